@@ -1,0 +1,213 @@
+/*
+ * o3dr.h — C ABI of libo3dr, the MI355X (gfx950) implementation of the per-frame
+ * reconstruction hot path of pk17r/online_3d_reconstruction:
+ *
+ *   disparity image -> 3D back-projection through Q -> rigid transform into the
+ *   world frame -> voxel-grid downsample -> accumulate -> 2.5-D global merge.
+ *
+ * The reference has no FFI/plugin interface; the seam is four `Pose` member
+ * functions plus the fan-out/accumulate loop around them.  Every entry point
+ * below names the reference interface (file:line under the reference tree) it
+ * replaces.  Plain pointers and sizes only: no C++, HIP or torch types.
+ *
+ * Conventions
+ *   - every function returns O3DR_OK (0) or a negative O3DR_ERR_* code; on error
+ *     every `n_out` is set to 0 ("output cloud left empty", pose.cpp:620-635).
+ *   - `mem` says where ALL data pointers of that call live: O3DR_MEM_HOST
+ *     (the library stages them through pinned buffers) or O3DR_MEM_DEVICE
+ *     (HBM pointers of the context's device; nothing is copied).  Small
+ *     parameter arrays (Q, poses of the single-frame calls, leaf) are always
+ *     host pointers; the batched `o3dr_accumulate_frames` takes its pose array
+ *     in `mem` like the images.
+ *   - images are OpenCV-layout: disparity CV_8UC1 row-major with a byte pitch,
+ *     colour CV_8UC3 interleaved B,G,R with a byte pitch (pose_functions.cpp:526,548).
+ *   - points are 16 bytes: x,y,z float + packed colour (a<<24|r<<16|g<<8|b), the
+ *     same packing pose_functions.cpp:1120-1121 stores in PointXYZRGB::rgb.
+ *   - 4x4 matrices are ROW-major float[16] (only the top three rows are read),
+ *     Q is ROW-major double[16] (pose.h:128, cam13calib.yml:91-97).
+ *   - a context is single-threaded; the reference's 7 concurrent callers
+ *     (pose.cpp:392-413) each own a context.  Work is issued on the context's
+ *     stream; calls with host outputs synchronise before returning, calls with
+ *     device outputs that report a count synchronise only for that count.
+ */
+#ifndef O3DR_H
+#define O3DR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define O3DR_VERSION 100 /* 0.1.0 */
+
+/* return codes */
+#define O3DR_OK                  0
+#define O3DR_ERR_INVALID_ARG    -1
+#define O3DR_ERR_NO_DEVICE      -2 /* no usable gfx950 device / HIP runtime failure at create */
+#define O3DR_ERR_HIP            -3 /* a HIP call failed; o3dr_last_error() has the text */
+#define O3DR_ERR_CAPACITY       -4 /* caller's output buffer is too small */
+#define O3DR_ERR_NOT_CONFIGURED -5 /* o3dr_set_camera not called yet */
+#define O3DR_ERR_ALLOC          -6
+
+/* `mem` values */
+#define O3DR_MEM_HOST   0
+#define O3DR_MEM_DEVICE 1
+
+/* bits of `*status` */
+#define O3DR_STATUS_VOXEL_OVERFLOW 1u /* PCL VoxelGrid "Leaf size is too small ... Integer indices
+                                         would overflow": output = input, unfiltered [PCL 1.8
+                                         filters/impl/voxel_grid.hpp applyFilter] */
+
+typedef struct o3dr_point {
+    float    x, y, z;
+    uint32_t rgba;
+} o3dr_point;
+
+/* Hot-path parameters = the `Pose` members the four functions read. */
+typedef struct o3dr_params {
+    double   min_disparity;        /* pose.h:93  minDisparity = 64, strict '>' (pose_functions.cpp:1107) */
+    double   voxel_size;           /* pose.h:118 voxel_size = 0.1 */
+    int32_t  bounding_box;         /* pose.h:94  boundingBox = 20 */
+    int32_t  cutout_ratio;         /* pose.h:126 cutout_ratio = 8; cols_start_aft_cutout=(int)(cols/ratio) pose_functions.cpp:638 */
+    int32_t  jump_pixels;          /* pose.h:96  jump_pixels = 10; 0 = keypoints only, 1 = dense (no keypoint pass) */
+    uint32_t min_points_per_voxel; /* pose.h:108 = 1; only the combined merge uses it (pose_functions.cpp:1693) */
+    int32_t  dont_downsample;      /* --dont_downsample, pose.cpp:609 */
+    int32_t  sor_enable;           /* statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686).
+                                      0 = off (the measured GPU configs); 1 is reserved and
+                                      currently returns O3DR_ERR_INVALID_ARG */
+} o3dr_params;
+
+typedef struct o3dr_ctx o3dr_ctx; /* opaque */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int         o3dr_version(void);
+/* text of the last failure on the calling thread ("" if none) */
+const char* o3dr_last_error(void);
+/* fills *p with the reference defaults (pose.h:92-126) */
+void        o3dr_default_params(o3dr_params* p);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* One context = one stream + workspaces on device `device_id`.  Fails with O3DR_ERR_NO_DEVICE
+ * when there is no GPU: there is no CPU fallback behind this ABI. */
+int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx);
+int o3dr_ctx_destroy(o3dr_ctx* ctx);
+/* Issue work on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
+ * context's own stream. */
+int o3dr_ctx_set_stream(o3dr_ctx* ctx, void* hip_stream);
+int o3dr_ctx_synchronize(o3dr_ctx* ctx);
+/* Q of the rectified stereo pair: Pose::Q, pose.h:128, read at pose_functions.cpp:467-476 */
+int o3dr_set_camera(o3dr_ctx* ctx, const double Q[16]);
+int o3dr_set_params(o3dr_ctx* ctx, const o3dr_params* p);
+int o3dr_get_params(o3dr_ctx* ctx, o3dr_params* p);
+
+/* ---- A1: Pose::createSingleImgPtCloud (pose.h:198, pose_functions.cpp:1030-1134) ---------------
+ * Camera-frame cloud of one frame: keypoint pass (iff jump_pixels != 1; `kp_xy` = n_kp pairs of
+ * float KeyPoint::pt.x,.y, truncated to int like pose_functions.cpp:1061) followed by the row-major
+ * grid pass (iff jump_pixels > 0).  `out_capacity` must be >= o3dr_max_points(rows, cols) + n_kp. */
+int o3dr_create_single_img_pt_cloud(o3dr_ctx* ctx,
+                                    const uint8_t* disp, int64_t disp_pitch,
+                                    const uint8_t* bgr, int64_t bgr_pitch,
+                                    int32_t rows, int32_t cols,
+                                    const float* kp_xy, int32_t n_kp,
+                                    o3dr_point* out, int64_t out_capacity, int64_t* n_out,
+                                    int32_t mem);
+/* number of grid-pass candidates for the context's current params: Ny*Nx of SURVEY section 8 */
+int64_t o3dr_max_points(o3dr_ctx* ctx, int32_t rows, int32_t cols);
+
+/* ---- A2: Pose::transformPtCloud (pose.h:199, pose_functions.cpp:1358-1362) ----------------------
+ * out[i].xyz = T * in[i].xyz in fp32, ((m0*x + m1*y) + m2*z) + m3, no fused multiply-add
+ * [PCL 1.8 common/impl/transforms.hpp, dense branch]; colour copied.  in == out is allowed
+ * (the in-place re-transform of cloud_big after ICP, pose.cpp:353). */
+int o3dr_transform_pt_cloud(o3dr_ctx* ctx, const o3dr_point* in, int64_t n,
+                            const float T[16], o3dr_point* out, int32_t mem);
+
+/* ---- A1+A2 fused: what createAndTransformPtCloud does before downsampling (pose.cpp:603-607) -- */
+int o3dr_reproject_transform(o3dr_ctx* ctx,
+                             const uint8_t* disp, int64_t disp_pitch,
+                             const uint8_t* bgr, int64_t bgr_pitch,
+                             int32_t rows, int32_t cols,
+                             const float T[16],
+                             const float* kp_xy, int32_t n_kp,
+                             o3dr_point* out, int64_t out_capacity, int64_t* n_out,
+                             int32_t mem);
+
+/* ---- A4: pcl::VoxelGrid<PointXYZRGB>::applyFilter as used at pose_functions.cpp:1689-1700 ------
+ * One output point per occupied voxel with >= min_points points: fp32 centroid, truncated mean
+ * colour, ascending linear voxel index (x fastest, then y, then z).  `z_offset` is added to z in
+ * fp32 on load and subtracted in fp32 on store (pose_functions.cpp:1666,1702-1704; 0 = none).
+ * Points of one voxel are summed in input order (see DESIGN.md "summation order").
+ * `out_capacity` must be >= n_in (the overflow fallback returns the input unchanged). */
+int o3dr_voxel_grid(o3dr_ctx* ctx, const o3dr_point* in, int64_t n_in,
+                    const float leaf[3], uint32_t min_points, float z_offset,
+                    o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
+                    int32_t mem);
+
+/* ---- A3a / A5: Pose::downsamplePtCloud (pose.h:216, pose_functions.cpp:1654-1709) --------------
+ * combined == 0: per-frame mode, leaf (voxel_size/5)^3, min_points 0   (:1698)
+ * combined != 0: 2.5-D merge, z += 500, leaf (voxel_size, voxel_size, 1000),
+ *                min_points_per_voxel, z -= 500                        (:1666,1693-1694,1702-1704) */
+int o3dr_downsample_pt_cloud(o3dr_ctx* ctx, const o3dr_point* in, int64_t n_in, int32_t combined,
+                             o3dr_point* out, int64_t out_capacity, int64_t* n_out,
+                             uint32_t* status, int32_t mem);
+
+/* ---- A6: Pose::createAndTransformPtCloud (pose.h:231, pose.cpp:596-636) -------------------------
+ * A1 -> A2 -> (A3a unless dont_downsample) for one frame into a caller-owned cloud. */
+int o3dr_create_and_transform_pt_cloud(o3dr_ctx* ctx,
+                                       const uint8_t* disp, int64_t disp_pitch,
+                                       const uint8_t* bgr, int64_t bgr_pitch,
+                                       int32_t rows, int32_t cols,
+                                       const float T[16],
+                                       const float* kp_xy, int32_t n_kp,
+                                       o3dr_point* out, int64_t out_capacity, int64_t* n_out,
+                                       uint32_t* status, int32_t mem);
+
+/* ---- A7: fan-out + accumulate (pose.cpp:365-434) and the final merge (pose.cpp:527-532) --------
+ * The context owns `cloud_big` in HBM.  o3dr_accumulate_frames runs A6 for `n_frames` frames
+ * (frame f at base + f*frame_stride; pose f at poses + 16*f) and appends the per-frame results in
+ * frame order, entirely on the device and asynchronously (no host round trip per frame).  No
+ * keypoint pass here: callers that need one use the single-frame entry points.
+ * `status_or` (host pointer, may be NULL) is written by o3dr_cloud_big_size/o3dr_finalize. */
+int o3dr_accumulate_frames(o3dr_ctx* ctx,
+                           const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
+                           const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch,
+                           int32_t rows, int32_t cols,
+                           const float* poses, int32_t n_frames, int32_t mem);
+/* reserve HBM for cloud_big (points); optional — it grows on demand */
+int o3dr_cloud_big_reserve(o3dr_ctx* ctx, int64_t n_points);
+int o3dr_cloud_big_reset(o3dr_ctx* ctx);
+/* synchronises; *status = OR of the per-frame O3DR_STATUS_* bits since the last reset */
+int o3dr_cloud_big_size(o3dr_ctx* ctx, int64_t* n, uint32_t* status);
+int o3dr_cloud_big_read(o3dr_ctx* ctx, o3dr_point* out, int64_t out_capacity, int64_t* n_out, int32_t mem);
+/* append externally produced points (a peer rank's shard after the RCCL all-gather, or a PLY) */
+int o3dr_cloud_big_append(o3dr_ctx* ctx, const o3dr_point* pts, int64_t n, int32_t mem);
+/* in-place rigid re-transform of cloud_big (pose.cpp:353) */
+int o3dr_cloud_big_transform(o3dr_ctx* ctx, const float T[16]);
+/* cloud_small = downsamplePtCloud(cloud_big, true) (pose.cpp:530); cloud_big is left intact */
+int o3dr_finalize(o3dr_ctx* ctx, o3dr_point* out, int64_t out_capacity, int64_t* n_out,
+                  uint32_t* status, int32_t mem);
+
+/* ---- measurement hooks (bench.py; not part of the reference surface) ------------------------ */
+/* kernel ids for o3dr_profile_* */
+#define O3DR_K_COUNT        0  /* grid-pass valid count per tile */
+#define O3DR_K_REPROJECT    1  /* fused reproject + SE(3) + ordered compaction */
+#define O3DR_K_KEYGEN       2  /* voxel linear index per point */
+#define O3DR_K_SORT_HIST    3  /* radix digit histogram */
+#define O3DR_K_SORT_SCATTER 4  /* radix stable scatter */
+#define O3DR_K_SEGMENT      5  /* voxel run heads + counts */
+#define O3DR_K_CENTROID     6  /* ordered per-voxel sums -> centroid */
+#define O3DR_K_OTHER        7  /* scans, grid setup, copies */
+#define O3DR_K_NUM          8
+/* Bracket every launch of kernel `kernel_id` (or all kernels if -1) with HIP events on the
+ * context's stream; 0 launches are bracketed when disabled (the default). */
+int o3dr_profile_enable(o3dr_ctx* ctx, int32_t kernel_id, int32_t enable);
+/* Synchronises; total milliseconds and launch count of `kernel_id` since enable/reset. */
+int o3dr_profile_read(o3dr_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
+int o3dr_profile_reset(o3dr_ctx* ctx);
+/* device name / arch / CU count of the context's device, for bench headers */
+int o3dr_device_info(o3dr_ctx* ctx, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3DR_H */

@@ -1,0 +1,304 @@
+"""Python mirror of the reference's operator surface for the hot path.
+
+`Context` methods carry the reference's member-function names (pose.h:198,199,216,231):
+createSingleImgPtCloud, transformPtCloud, downsamplePtCloud, createAndTransformPtCloud — plus the
+fan-out/accumulate loop (pose.cpp:365-434) and the final merge (pose.cpp:527-532).  All compute
+happens in libo3dr.so; numpy arrays are staged by the library, torch CUDA tensors are passed as
+HBM pointers (torch is only device memory + streams here).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import POINT
+
+
+@dataclass
+class Params:
+    """The `Pose` members the hot path reads (pose.h:93-126), reference defaults."""
+    min_disparity: float = 64.0
+    voxel_size: float = 0.1
+    bounding_box: int = 20
+    cutout_ratio: int = 8
+    jump_pixels: int = 10
+    min_points_per_voxel: int = 1
+    dont_downsample: bool = False
+    sor_enable: bool = False
+
+    def to_struct(self):
+        return L.ParamsStruct(float(self.min_disparity), float(self.voxel_size), int(self.bounding_box),
+                              int(self.cutout_ratio), int(self.jump_pixels), int(self.min_points_per_voxel),
+                              int(bool(self.dont_downsample)), int(bool(self.sor_enable)))
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    """(address, MEM kind, keepalive) of a numpy array or a torch tensor."""
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return x.data_ptr(), (L.MEM_DEVICE if x.is_cuda else L.MEM_HOST), x
+    return x.ctypes.data, L.MEM_HOST, x
+
+
+class Context:
+    def __init__(self, device=0, Q=None, params=None, stream=None):
+        self._lib = L.load_library()
+        h = C.c_void_p()
+        L.check(self._lib.o3dr_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.params = Params()
+        if Q is not None:
+            self.set_camera(Q)
+        if params is not None:
+            self.set_params(params)
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.o3dr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- configuration ----------------------------------------------------------------------------
+    def set_camera(self, Q):
+        Q = np.ascontiguousarray(Q, np.float64).reshape(16)
+        L.check(self._lib.o3dr_set_camera(self._h, Q.ctypes.data))
+
+    def set_params(self, params):
+        s = params.to_struct()
+        L.check(self._lib.o3dr_set_params(self._h, C.byref(s)))
+        self.params = params
+
+    def set_stream(self, stream):
+        """stream: a torch.cuda.Stream, a raw hipStream_t integer, or None for the context's own."""
+        raw = getattr(stream, "cuda_stream", stream)
+        L.check(self._lib.o3dr_ctx_set_stream(self._h, C.c_void_p(raw or 0)))
+
+    def synchronize(self):
+        L.check(self._lib.o3dr_ctx_synchronize(self._h))
+
+    def max_points(self, rows, cols):
+        return int(self._lib.o3dr_max_points(self._h, rows, cols))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, mem = C.c_int32(0), C.c_int64(0)
+        L.check(self._lib.o3dr_device_info(self._h, name, 256, C.byref(cu), C.byref(mem)))
+        return name.value.decode(), cu.value, mem.value
+
+    # -- helpers ----------------------------------------------------------------------------------
+    @staticmethod
+    def _images(disp, bgr):
+        if _is_torch(disp):
+            rows, cols = disp.shape
+            assert tuple(bgr.shape) == (rows, cols, 3)
+            return rows, cols, disp.stride(0), bgr.stride(0)
+        rows, cols = disp.shape
+        assert disp.dtype == np.uint8 and bgr.dtype == np.uint8 and bgr.shape == (rows, cols, 3)
+        assert disp.strides[1] == 1 and bgr.strides[2] == 1 and bgr.strides[1] == 3
+        return rows, cols, disp.strides[0], bgr.strides[0]
+
+    def _alloc_out(self, n, like):
+        if _is_torch(like) and like.is_cuda:
+            import torch
+            return torch.empty((max(n, 1), 4), dtype=torch.int32, device=like.device)
+        return np.empty(max(n, 1), POINT)
+
+    @staticmethod
+    def _kp(kp_xy, like):
+        if kp_xy is None:
+            return 0, 0, None
+        if _is_torch(kp_xy):
+            return kp_xy.data_ptr(), int(kp_xy.shape[0]), kp_xy
+        kp = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+        if _is_torch(like) and like.is_cuda:
+            import torch
+            t = torch.from_numpy(kp).to(like.device)
+            return t.data_ptr(), len(kp), t
+        return kp.ctypes.data, len(kp), kp
+
+    @staticmethod
+    def _T(T):
+        return np.ascontiguousarray(T, np.float32).reshape(16)
+
+    def _frame(self, fn_name, disp, bgr, T, kp_xy, with_status):
+        rows, cols, dp, bp = self._images(disp, bgr)
+        pd, mem, _k1 = _ptr(disp)
+        pb, mem2, _k2 = _ptr(bgr)
+        assert mem == mem2
+        kp_ptr, n_kp, _k3 = self._kp(kp_xy, disp)
+        cap = self.max_points(rows, cols) + n_kp
+        out = self._alloc_out(cap, disp)
+        po, _, _k4 = _ptr(out)
+        n = C.c_int64(0)
+        st = C.c_uint32(0)
+        fn = getattr(self._lib, fn_name)
+        args = [self._h, pd, dp, pb, bp, rows, cols]
+        if T is not None:
+            Tn = self._T(T)
+            args.append(Tn.ctypes.data)
+        args += [kp_ptr, n_kp, po, cap, C.byref(n)]
+        if with_status:
+            args.append(C.byref(st))
+        args.append(mem)
+        L.check(fn(*args))
+        return out[: n.value], st.value
+
+    # -- the reference's four entry points ---------------------------------------------------------
+    def createSingleImgPtCloud(self, disp, bgr, kp_xy=None):
+        """pose.h:198 / pose_functions.cpp:1030-1134 (camera-frame cloud of one frame)."""
+        return self._frame("o3dr_create_single_img_pt_cloud", disp, bgr, None, kp_xy, False)[0]
+
+    def transformPtCloud(self, pts, T):
+        """pose.h:199 / pose_functions.cpp:1358-1362."""
+        Tn = self._T(T)
+        if not _is_torch(pts):
+            pts = np.ascontiguousarray(pts, POINT)
+        pi, mem, _k = _ptr(pts)
+        n = int(pts.shape[0])
+        out = self._alloc_out(n, pts)
+        po, _, _k2 = _ptr(out)
+        L.check(self._lib.o3dr_transform_pt_cloud(self._h, pi, n, Tn.ctypes.data, po, mem))
+        return out[:n]
+
+    def reprojectTransform(self, disp, bgr, T, kp_xy=None):
+        """A1+A2 fused: createSingleImgPtCloud followed by transformPtCloud (pose.cpp:603-607)."""
+        return self._frame("o3dr_reproject_transform", disp, bgr, T, kp_xy, False)[0]
+
+    def downsamplePtCloud(self, pts, combinedPtCloud, return_status=False):
+        """pose.h:216 / pose_functions.cpp:1654-1709."""
+        if not _is_torch(pts):
+            pts = np.ascontiguousarray(pts, POINT)
+        pi, mem, _k = _ptr(pts)
+        n_in = int(pts.shape[0])
+        out = self._alloc_out(n_in, pts)
+        po, _, _k2 = _ptr(out)
+        n = C.c_int64(0)
+        st = C.c_uint32(0)
+        L.check(self._lib.o3dr_downsample_pt_cloud(self._h, pi, n_in, int(bool(combinedPtCloud)), po, max(n_in, 1),
+                                                  C.byref(n), C.byref(st), mem))
+        return (out[: n.value], st.value) if return_status else out[: n.value]
+
+    def voxelGrid(self, pts, leaf, min_points=0, z_offset=0.0, return_status=False):
+        """pcl::VoxelGrid<PointXYZRGB> as the reference configures it (pose_functions.cpp:1689-1700)."""
+        if not _is_torch(pts):
+            pts = np.ascontiguousarray(pts, POINT)
+        leaf = np.ascontiguousarray(leaf, np.float32).reshape(3)
+        pi, mem, _k = _ptr(pts)
+        n_in = int(pts.shape[0])
+        out = self._alloc_out(n_in, pts)
+        po, _, _k2 = _ptr(out)
+        n = C.c_int64(0)
+        st = C.c_uint32(0)
+        L.check(self._lib.o3dr_voxel_grid(self._h, pi, n_in, leaf.ctypes.data, int(min_points), float(z_offset), po,
+                                         max(n_in, 1), C.byref(n), C.byref(st), mem))
+        return (out[: n.value], st.value) if return_status else out[: n.value]
+
+    def createAndTransformPtCloud(self, disp, bgr, T, kp_xy=None, return_status=False):
+        """pose.h:231 / pose.cpp:596-636."""
+        out, st = self._frame("o3dr_create_and_transform_pt_cloud", disp, bgr, T, kp_xy, True)
+        return (out, st) if return_status else out
+
+    # -- fan-out / accumulate / final merge ---------------------------------------------------------
+    def accumulateFrames(self, disp, bgr, poses):
+        """pose.cpp:365-434 for a stack of frames: disp [F,H,W] u8, bgr [F,H,W,3] u8, poses [F,4,4] f32."""
+        F, rows, cols = disp.shape
+        if _is_torch(disp):
+            assert disp.is_contiguous() and bgr.is_contiguous() and poses.is_contiguous()
+            dfs, dp, bfs, bp = disp.stride(0), disp.stride(1), bgr.stride(0), bgr.stride(1)
+            assert poses.dtype.__str__() == "torch.float32" and poses.numel() == F * 16
+        else:
+            disp = np.ascontiguousarray(disp, np.uint8)
+            bgr = np.ascontiguousarray(bgr, np.uint8)
+            poses = np.ascontiguousarray(poses, np.float32).reshape(F, 16)
+            dfs, dp, bfs, bp = disp.strides[0], disp.strides[1], bgr.strides[0], bgr.strides[1]
+        pd, mem, _k1 = _ptr(disp)
+        pb, mem2, _k2 = _ptr(bgr)
+        pp, mem3, _k3 = _ptr(poses)
+        assert mem == mem2 == mem3
+        L.check(self._lib.o3dr_accumulate_frames(self._h, pd, dfs, dp, pb, bfs, bp, rows, cols, pp, F, mem))
+
+    def cloudBigReserve(self, n_points):
+        L.check(self._lib.o3dr_cloud_big_reserve(self._h, int(n_points)))
+
+    def cloudBigReset(self):
+        L.check(self._lib.o3dr_cloud_big_reset(self._h))
+
+    def cloudBigSize(self):
+        n = C.c_int64(0)
+        st = C.c_uint32(0)
+        L.check(self._lib.o3dr_cloud_big_size(self._h, C.byref(n), C.byref(st)))
+        return n.value, st.value
+
+    def cloudBigRead(self, device=None):
+        n, _ = self.cloudBigSize()
+        if device is not None:
+            import torch
+            out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
+        else:
+            out = np.empty(max(n, 1), POINT)
+        po, mem, _k = _ptr(out)
+        m = C.c_int64(0)
+        L.check(self._lib.o3dr_cloud_big_read(self._h, po, max(n, 1), C.byref(m), mem))
+        return out[: m.value]
+
+    def cloudBigAppend(self, pts):
+        if not _is_torch(pts):
+            pts = np.ascontiguousarray(pts, POINT)
+        pi, mem, _k = _ptr(pts)
+        L.check(self._lib.o3dr_cloud_big_append(self._h, pi, int(pts.shape[0]), mem))
+
+    def cloudBigTransform(self, T):
+        Tn = self._T(T)
+        L.check(self._lib.o3dr_cloud_big_transform(self._h, Tn.ctypes.data))
+
+    def finalize(self, device=None, return_status=False):
+        """cloud_small = downsamplePtCloud(cloud_big, true) (pose.cpp:530)."""
+        n, _ = self.cloudBigSize()
+        if device is not None:
+            import torch
+            out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
+        else:
+            out = np.empty(max(n, 1), POINT)
+        po, mem, _k = _ptr(out)
+        m = C.c_int64(0)
+        st = C.c_uint32(0)
+        L.check(self._lib.o3dr_finalize(self._h, po, max(n, 1), C.byref(m), C.byref(st), mem))
+        return (out[: m.value], st.value) if return_status else out[: m.value]
+
+    # -- measurement hooks --------------------------------------------------------------------------
+    def profileEnable(self, kernel_id=-1, enable=True):
+        L.check(self._lib.o3dr_profile_enable(self._h, int(kernel_id), int(bool(enable))))
+
+    def profileReset(self):
+        L.check(self._lib.o3dr_profile_reset(self._h))
+
+    def profileRead(self, kernel_id):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        L.check(self._lib.o3dr_profile_read(self._h, int(kernel_id), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def points_from_torch(t):
+    """[N,4] int32 CUDA/CPU tensor -> numpy POINT array (host copy)."""
+    return t.detach().cpu().numpy().view(POINT).reshape(-1)

@@ -1,0 +1,913 @@
+// o3dr_api.hip — the C ABI of include/o3dr.h on top of the kernels in o3dr_kernels.hip.
+//
+// Host-side responsibilities only: argument checking, HBM workspaces, staging of host buffers,
+// batching of frames, the device-resident cloud_big, error codes.  There is no CPU compute path:
+// without a GPU o3dr_ctx_create fails and nothing else can be called.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "o3dr_device.h"
+#include "o3dr_profile.h"
+
+using namespace o3dr;
+
+// -------------------------------------------------------------------------------------------------
+// errors
+// -------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* what)
+{
+    g_err = what;
+    return code;
+}
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            char buf_[512];                                                                      \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            g_err = buf_;                                                                        \
+            return O3DR_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+#define CHK(expr)                  \
+    do {                           \
+        int r_ = (expr);           \
+        if (r_ != O3DR_OK) return r_; \
+    } while (0)
+
+// -------------------------------------------------------------------------------------------------
+// context
+// -------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct o3dr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    o3dr_params params;
+    double Q[16];
+    bool has_Q = false;
+    int max_batch = 32;
+
+    Workspace ws;
+    size_t ws_elems = 0;   // frames*(cap+1) the per-point arrays were allocated for
+    size_t ws_pts_elems = 0;
+    int ws_frames = 0;
+    size_t ws_emit_tiles = 0, ws_sort_tiles = 0, ws_seg_tiles = 0;
+    DevBuf ws_block, ws_pts_block;
+
+    // accumulating cloud (pose.cpp:434 cloud_big)
+    o3dr_point* cloud_big = nullptr;
+    int64_t cloud_cap = 0;
+    int64_t cloud_ub = 0;          // host-side upper bound of cc_big->count
+    CloudCounters* cc_big = nullptr;   // device
+    CloudCounters* cc_tmp = nullptr;   // device, for single-shot calls
+    CloudCounters* cc_host = nullptr;  // pinned
+    uint32_t* n_host = nullptr;        // pinned scratch (4 words)
+
+    DevBuf st_disp, st_bgr, st_in, st_out, st_kp, st_poses;
+    Profiler prof;
+};
+
+static int dev_ensure(o3dr_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return O3DR_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes;
+        if (hipMalloc(&b.p, want) != hipSuccess) {
+            b.p = nullptr;
+            return fail(O3DR_ERR_ALLOC, "hipMalloc failed (workspace)");
+        }
+    }
+    b.cap = want;
+    return O3DR_OK;
+}
+static void dev_release(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// (re)carve the per-batch workspace for `frames` clouds of at most `cap` points
+static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
+{
+    if (cap < 1) cap = 1;
+    const size_t elems = (size_t)frames * (size_t)(cap + 1);
+    const size_t emit_tiles = (size_t)frames * (size_t)((cap + kEmitTile - 1) / kEmitTile);
+    const size_t sort_tiles = (size_t)frames * (size_t)((cap + kSortTile - 1) / kSortTile);
+    const size_t seg_tiles = (size_t)frames * (size_t)((cap + kSegTile - 1) / kSegTile);
+    if (elems > c->ws_elems || frames > c->ws_frames || emit_tiles > c->ws_emit_tiles ||
+        sort_tiles > c->ws_sort_tiles || seg_tiles > c->ws_seg_tiles) {
+        const size_t E = elems > c->ws_elems ? elems : c->ws_elems;
+        const int F = frames > c->ws_frames ? frames : c->ws_frames;
+        const size_t TE = emit_tiles > c->ws_emit_tiles ? emit_tiles : c->ws_emit_tiles;
+        const size_t TS = sort_tiles > c->ws_sort_tiles ? sort_tiles : c->ws_sort_tiles;
+        const size_t TG = seg_tiles > c->ws_seg_tiles ? seg_tiles : c->ws_seg_tiles;
+        size_t off = 0;
+        size_t o_keys0 = off; off += align256(E * 4);
+        size_t o_keys1 = off; off += align256(E * 4);
+        size_t o_vals0 = off; off += align256(E * 4);
+        size_t o_vals1 = off; off += align256(E * 4);
+        size_t o_seg = off;   off += align256(E * 4);
+        size_t o_tile = off;  off += align256(TE * 4);
+        size_t o_hist = off;  off += align256(TS * kRadix * 4);
+        size_t o_segc = off;  off += align256(TG * 4);
+        size_t o_mm = off;    off += align256((size_t)F * 6 * 4);
+        size_t o_nv = off;    off += align256((size_t)F * 4);
+        size_t o_nk = off;    off += align256((size_t)F * 4);
+        size_t o_nx = off;    off += align256((size_t)F * 4);
+        size_t o_no = off;    off += align256((size_t)F * 4);
+        size_t o_oo = off;    off += align256((size_t)F * 8);
+        size_t o_geom = off;  off += align256((size_t)F * sizeof(VoxelGeom));
+        CHK(dev_ensure(c, c->ws_block, off));
+        char* base = (char*)c->ws_block.p;
+        Workspace& w = c->ws;
+        w.keys[0] = (uint32_t*)(base + o_keys0);
+        w.keys[1] = (uint32_t*)(base + o_keys1);
+        w.vals[0] = (uint32_t*)(base + o_vals0);
+        w.vals[1] = (uint32_t*)(base + o_vals1);
+        w.seg_start = (uint32_t*)(base + o_seg);
+        w.keep_idx = w.keys[1];  // free once the 4-pass sort has landed back in buffer 0
+        w.tile_cnt = (uint32_t*)(base + o_tile);
+        w.hist = (uint32_t*)(base + o_hist);
+        w.seg_cnt = (uint32_t*)(base + o_segc);
+        w.minmax = (uint32_t*)(base + o_mm);
+        w.n_valid = (uint32_t*)(base + o_nv);
+        w.n_kp = (uint32_t*)(base + o_nk);
+        w.n_vox = (uint32_t*)(base + o_nx);
+        w.n_out = (uint32_t*)(base + o_no);
+        w.out_off = (uint64_t*)(base + o_oo);
+        w.geom = (VoxelGeom*)(base + o_geom);
+        w.bytes = off;
+        c->ws_elems = E;
+        c->ws_frames = F;
+        c->ws_emit_tiles = TE;
+        c->ws_sort_tiles = TS;
+        c->ws_seg_tiles = TG;
+    }
+    if (need_pts) {
+        const size_t pe = (size_t)frames * (size_t)cap;
+        if (pe > c->ws_pts_elems) {
+            CHK(dev_ensure(c, c->ws_pts_block, pe * sizeof(o3dr_point)));
+            c->ws_pts_elems = pe;
+        }
+        c->ws.pts = (o3dr_point*)c->ws_pts_block.p;
+    }
+    c->ws.frames = frames;
+    c->ws.cap = cap;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_version(void) { return O3DR_VERSION; }
+extern "C" const char* o3dr_last_error(void) { return g_err.c_str(); }
+
+extern "C" void o3dr_default_params(o3dr_params* p)
+{
+    if (!p) return;
+    p->min_disparity = 64;          // pose.h:93
+    p->voxel_size = 0.1;            // pose.h:118
+    p->bounding_box = 20;           // pose.h:94
+    p->cutout_ratio = 8;            // pose.h:126
+    p->jump_pixels = 10;            // pose.h:96
+    p->min_points_per_voxel = 1;    // pose.h:108
+    p->dont_downsample = 0;
+    p->sor_enable = 0;
+}
+
+extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
+{
+    if (!out_ctx) return fail(O3DR_ERR_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(O3DR_ERR_NO_DEVICE, "no HIP device: libo3dr has no CPU path");
+    }
+    if (device_id < 0 || device_id >= n) return fail(O3DR_ERR_INVALID_ARG, "device_id out of range");
+    if (hipSetDevice(device_id) != hipSuccess) return fail(O3DR_ERR_NO_DEVICE, "hipSetDevice failed");
+    o3dr_ctx* c = new o3dr_ctx();
+    c->device = device_id;
+    o3dr_default_params(&c->params);
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(O3DR_ERR_NO_DEVICE, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    if (hipMalloc((void**)&c->cc_big, sizeof(CloudCounters)) != hipSuccess ||
+        hipMalloc((void**)&c->cc_tmp, sizeof(CloudCounters)) != hipSuccess ||
+        hipHostMalloc((void**)&c->cc_host, sizeof(CloudCounters), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->n_host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return fail(O3DR_ERR_ALLOC, "counter allocation failed");
+    }
+    (void)hipMemsetAsync(c->cc_big, 0, sizeof(CloudCounters), c->stream);
+    (void)hipMemsetAsync(c->cc_tmp, 0, sizeof(CloudCounters), c->stream);
+    const char* env = getenv("O3DR_BATCH_FRAMES");
+    if (env && atoi(env) > 0) c->max_batch = atoi(env) > 64 ? 64 : atoi(env);
+    *out_ctx = c;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
+{
+    if (!c) return O3DR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    dev_release(c->ws_block);
+    dev_release(c->ws_pts_block);
+    dev_release(c->st_disp);
+    dev_release(c->st_bgr);
+    dev_release(c->st_in);
+    dev_release(c->st_out);
+    dev_release(c->st_kp);
+    dev_release(c->st_poses);
+    if (c->cloud_big) (void)hipFree(c->cloud_big);
+    if (c->cc_big) (void)hipFree(c->cc_big);
+    if (c->cc_tmp) (void)hipFree(c->cc_tmp);
+    if (c->cc_host) (void)hipHostFree(c->cc_host);
+    if (c->n_host) (void)hipHostFree(c->n_host);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return O3DR_OK;
+}
+
+#define CTX_ENTER(c)                                                        \
+    do {                                                                    \
+        if (!(c)) return fail(O3DR_ERR_INVALID_ARG, "ctx is NULL");         \
+        HIPCHK(hipSetDevice((c)->device));                                  \
+    } while (0)
+
+extern "C" int o3dr_ctx_set_stream(o3dr_ctx* c, void* hip_stream)
+{
+    CTX_ENTER(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return O3DR_OK;
+}
+extern "C" int o3dr_ctx_synchronize(o3dr_ctx* c)
+{
+    CTX_ENTER(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return O3DR_OK;
+}
+extern "C" int o3dr_set_camera(o3dr_ctx* c, const double Q[16])
+{
+    CTX_ENTER(c);
+    if (!Q) return fail(O3DR_ERR_INVALID_ARG, "Q is NULL");
+    memcpy(c->Q, Q, sizeof c->Q);
+    c->has_Q = true;
+    return O3DR_OK;
+}
+extern "C" int o3dr_set_params(o3dr_ctx* c, const o3dr_params* p)
+{
+    CTX_ENTER(c);
+    if (!p) return fail(O3DR_ERR_INVALID_ARG, "params is NULL");
+    if (p->bounding_box < 0 || p->cutout_ratio <= 0 || p->jump_pixels < 0 || !(p->voxel_size > 0))
+        return fail(O3DR_ERR_INVALID_ARG, "params out of range");
+    if (p->sor_enable) return fail(O3DR_ERR_INVALID_ARG, "sor_enable=1 is not implemented (SURVEY 8f-1)");
+    c->params = *p;
+    return O3DR_OK;
+}
+extern "C" int o3dr_get_params(o3dr_ctx* c, o3dr_params* p)
+{
+    CTX_ENTER(c);
+    if (!p) return fail(O3DR_ERR_INVALID_ARG, "params is NULL");
+    *p = c->params;
+    return O3DR_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// helpers
+// -------------------------------------------------------------------------------------------------
+struct GridShape {
+    int cs, Ny, Nx;
+    int64_t n;
+};
+// pose_functions.cpp:638 and the loop bounds of :1094-1096
+static GridShape grid_shape(const o3dr_params& p, int rows, int cols)
+{
+    GridShape g;
+    g.cs = (int)(cols / p.cutout_ratio);
+    g.Ny = g.Nx = 0;
+    if (p.jump_pixels > 0) {
+        const int h = rows - 2 * p.bounding_box, w = cols - p.bounding_box - g.cs;
+        g.Ny = h > 0 ? (h + p.jump_pixels - 1) / p.jump_pixels : 0;
+        g.Nx = w > 0 ? (w + p.jump_pixels - 1) / p.jump_pixels : 0;
+    }
+    g.n = (int64_t)g.Ny * g.Nx;
+    return g;
+}
+
+extern "C" int64_t o3dr_max_points(o3dr_ctx* c, int32_t rows, int32_t cols)
+{
+    if (!c) return 0;
+    return grid_shape(c->params, rows, cols).n;
+}
+
+static int check_images(const uint8_t* disp, int64_t disp_pitch, const uint8_t* bgr, int64_t bgr_pitch, int rows,
+                        int cols)
+{
+    if (!disp || !bgr) return fail(O3DR_ERR_INVALID_ARG, "image pointer is NULL");
+    if (rows <= 0 || cols <= 0) return fail(O3DR_ERR_INVALID_ARG, "rows/cols must be positive");
+    if (disp_pitch < cols || bgr_pitch < 3 * (int64_t)cols) return fail(O3DR_ERR_INVALID_ARG, "pitch smaller than a row");
+    return O3DR_OK;
+}
+
+static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_t disp_pitch, int64_t disp_fstride,
+                      const uint8_t* bgr, int64_t bgr_pitch, int64_t bgr_fstride, int rows, int cols,
+                      const GridShape& g, int64_t out_fstride)
+{
+    memset(&a, 0, sizeof a);
+    a.disp = disp;
+    a.bgr = bgr;
+    a.disp_pitch = disp_pitch;
+    a.bgr_pitch = bgr_pitch;
+    a.disp_fstride = disp_fstride;
+    a.bgr_fstride = bgr_fstride;
+    a.rows = rows;
+    a.cols = cols;
+    a.bb = c->params.bounding_box;
+    a.cs = g.cs;
+    a.jump = c->params.jump_pixels;
+    a.Ny = g.Ny;
+    a.Nx = g.Nx;
+    a.n_tiles = (int)((g.n + kEmitTile - 1) / kEmitTile);
+    a.vec4 = (a.jump == 1 && (g.Nx % 4) == 0 && (g.cs % 4) == 0 && (disp_pitch % 4) == 0 && (bgr_pitch % 4) == 0 &&
+              (disp_fstride % 4) == 0 && (bgr_fstride % 4) == 0 && ((uintptr_t)disp % 4) == 0 &&
+              ((uintptr_t)bgr % 4) == 0)
+                 ? 1
+                 : 0;
+    memcpy(a.Q, c->Q, sizeof a.Q);
+    a.min_disp = c->params.min_disparity;
+    a.out_fstride = out_fstride;
+}
+
+// stage a host buffer into HBM (or pass a device pointer through)
+static int stage_in(o3dr_ctx* c, DevBuf& b, const void* src, size_t bytes, int mem, const void** dev)
+{
+    if (mem == O3DR_MEM_DEVICE) {
+        *dev = src;
+        return O3DR_OK;
+    }
+    CHK(dev_ensure(c, b, bytes ? bytes : 1));
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = b.p;
+    return O3DR_OK;
+}
+
+// read a CloudCounters back (synchronises)
+static int read_counters(o3dr_ctx* c, const CloudCounters* dev, CloudCounters* host)
+{
+    HIPCHK(hipMemcpyAsync(c->cc_host, dev, sizeof(CloudCounters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *host = *c->cc_host;
+    return O3DR_OK;
+}
+
+static int zero_counters(o3dr_ctx* c, CloudCounters* dev)
+{
+    HIPCHK(hipMemsetAsync(dev, 0, sizeof(CloudCounters), c->stream));
+    return O3DR_OK;
+}
+
+// A1 (+A2) of one frame into `dst` (device).  n_valid ends up in ws.n_valid[0].
+static int run_reproject_single(o3dr_ctx* c, const uint8_t* disp_d, int64_t disp_pitch, const uint8_t* bgr_d,
+                                int64_t bgr_pitch, int rows, int cols, const GridShape& g, const float* T,
+                                const float* kp_d, int n_kp, o3dr_point* dst)
+{
+    ReprojectArgs a;
+    fill_args(c, a, disp_d, disp_pitch, 0, bgr_d, bgr_pitch, 0, rows, cols, g, 0);
+    if (T) {
+        a.xf_mode = 1;
+        for (int i = 0; i < 12; ++i) a.T[i] = T[i];
+    }
+    launch_minmax_init(&c->prof, c->stream, c->ws.minmax, c->ws.n_kp, 1);
+    if (c->params.jump_pixels != 1 && n_kp > 0)
+        launch_keypoint_pass(&c->prof, c->stream, a, kp_d, n_kp, dst, c->ws.n_kp, c->ws.minmax);
+    launch_reproject(&c->prof, c->stream, a, 1, dst, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.minmax);
+    HIPCHK(hipGetLastError());
+    return O3DR_OK;
+}
+
+static int read_u32(o3dr_ctx* c, const uint32_t* dev, uint32_t* host)
+{
+    HIPCHK(hipMemcpyAsync(c->n_host, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *host = c->n_host[0];
+    return O3DR_OK;
+}
+
+// common body of A1, A1+A2 and A6
+static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, const uint8_t* bgr, int64_t bgr_pitch,
+                      int rows, int cols, const float* T, const float* kp_xy, int n_kp, bool downsample,
+                      o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status, int mem)
+{
+    if (n_out) *n_out = 0;
+    if (status) *status = 0;
+    CTX_ENTER(c);
+    if (!c->has_Q) return fail(O3DR_ERR_NOT_CONFIGURED, "o3dr_set_camera has not been called");
+    if (!n_out || !out) return fail(O3DR_ERR_INVALID_ARG, "out / n_out is NULL");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    CHK(check_images(disp, disp_pitch, bgr, bgr_pitch, rows, cols));
+    if (n_kp < 0 || (n_kp > 0 && !kp_xy)) return fail(O3DR_ERR_INVALID_ARG, "bad keypoint list");
+    if (c->params.jump_pixels == 1) n_kp = 0;  // :1057 keypoints are skipped when every pixel is taken
+    const GridShape g = grid_shape(c->params, rows, cols);
+    const int64_t cap = g.n + n_kp;
+    if (mem == O3DR_MEM_DEVICE && out_capacity < cap)
+        return fail(O3DR_ERR_CAPACITY, "device output must hold o3dr_max_points()+n_kp points");
+    if (cap == 0) return O3DR_OK;
+
+    const void *disp_d, *bgr_d, *kp_d = nullptr;
+    CHK(stage_in(c, c->st_disp, disp, (size_t)rows * disp_pitch, mem, &disp_d));
+    CHK(stage_in(c, c->st_bgr, bgr, (size_t)rows * bgr_pitch, mem, &bgr_d));
+    if (n_kp > 0) CHK(stage_in(c, c->st_kp, kp_xy, (size_t)n_kp * 2 * sizeof(float), mem, &kp_d));
+    CHK(ws_ensure(c, 1, cap, downsample));
+
+    o3dr_point* final_dst = out;
+    if (mem == O3DR_MEM_HOST) {
+        CHK(dev_ensure(c, c->st_out, (size_t)cap * sizeof(o3dr_point)));
+        final_dst = (o3dr_point*)c->st_out.p;
+    }
+    int64_t n_final = 0;
+    uint32_t st = 0;
+    if (!downsample) {
+        CHK(run_reproject_single(c, (const uint8_t*)disp_d, disp_pitch, (const uint8_t*)bgr_d, bgr_pitch, rows, cols, g,
+                                 T, (const float*)kp_d, n_kp, final_dst));
+        uint32_t nv = 0;
+        CHK(read_u32(c, c->ws.n_valid, &nv));
+        n_final = nv;
+    } else {
+        CHK(run_reproject_single(c, (const uint8_t*)disp_d, disp_pitch, (const uint8_t*)bgr_d, bgr_pitch, rows, cols, g,
+                                 T, (const float*)kp_d, n_kp, c->ws.pts));
+        CHK(zero_counters(c, c->cc_tmp));
+        VoxelArgs v;
+        v.in = c->ws.pts;
+        v.in_fstride = 0;
+        v.n_dev = c->ws.n_valid;
+        v.frames = 1;
+        v.cap = cap;
+        v.leaf[0] = v.leaf[1] = v.leaf[2] = (float)(c->params.voxel_size / 5);  // pose_functions.cpp:1698
+        v.min_points = 0;
+        v.z_offset = 0.f;
+        v.out_base = final_dst;
+        v.cc = c->cc_tmp;
+        v.passthrough = 0;
+        launch_voxel_grid(&c->prof, c->stream, c->ws, v);
+        HIPCHK(hipGetLastError());
+        CloudCounters cc;
+        CHK(read_counters(c, c->cc_tmp, &cc));
+        n_final = (int64_t)cc.count;
+        st = cc.status;
+    }
+    if (mem == O3DR_MEM_HOST) {
+        if (n_final > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+        if (n_final > 0) {
+            HIPCHK(hipMemcpyAsync(out, final_dst, (size_t)n_final * sizeof(o3dr_point), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    }
+    *n_out = n_final;
+    if (status) *status = st;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_create_single_img_pt_cloud(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, const uint8_t* bgr,
+                                               int64_t bgr_pitch, int32_t rows, int32_t cols, const float* kp_xy,
+                                               int32_t n_kp, o3dr_point* out, int64_t out_capacity, int64_t* n_out,
+                                               int32_t mem)
+{
+    return frame_call(c, disp, disp_pitch, bgr, bgr_pitch, rows, cols, nullptr, kp_xy, n_kp, false, out, out_capacity,
+                      n_out, nullptr, mem);
+}
+
+extern "C" int o3dr_reproject_transform(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, const uint8_t* bgr,
+                                        int64_t bgr_pitch, int32_t rows, int32_t cols, const float T[16],
+                                        const float* kp_xy, int32_t n_kp, o3dr_point* out, int64_t out_capacity,
+                                        int64_t* n_out, int32_t mem)
+{
+    if (!T) {
+        if (n_out) *n_out = 0;
+        return fail(O3DR_ERR_INVALID_ARG, "T is NULL");
+    }
+    return frame_call(c, disp, disp_pitch, bgr, bgr_pitch, rows, cols, T, kp_xy, n_kp, false, out, out_capacity, n_out,
+                      nullptr, mem);
+}
+
+extern "C" int o3dr_create_and_transform_pt_cloud(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch,
+                                                  const uint8_t* bgr, int64_t bgr_pitch, int32_t rows, int32_t cols,
+                                                  const float T[16], const float* kp_xy, int32_t n_kp, o3dr_point* out,
+                                                  int64_t out_capacity, int64_t* n_out, uint32_t* status, int32_t mem)
+{
+    if (!T) {
+        if (n_out) *n_out = 0;
+        return fail(O3DR_ERR_INVALID_ARG, "T is NULL");
+    }
+    const bool ds = c ? !c->params.dont_downsample : true;
+    return frame_call(c, disp, disp_pitch, bgr, bgr_pitch, rows, cols, T, kp_xy, n_kp, ds, out, out_capacity, n_out,
+                      status, mem);
+}
+
+extern "C" int o3dr_transform_pt_cloud(o3dr_ctx* c, const o3dr_point* in, int64_t n, const float T[16], o3dr_point* out,
+                                       int32_t mem)
+{
+    CTX_ENTER(c);
+    if (n < 0 || !T || (n > 0 && (!in || !out))) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    if (n == 0) return O3DR_OK;
+    if (mem == O3DR_MEM_DEVICE) {
+        launch_transform(&c->prof, c->stream, in, n, T, out);
+        HIPCHK(hipGetLastError());
+        return O3DR_OK;
+    }
+    const void* in_d;
+    CHK(stage_in(c, c->st_in, in, (size_t)n * sizeof(o3dr_point), mem, &in_d));
+    launch_transform(&c->prof, c->stream, (const o3dr_point*)in_d, n, T, (o3dr_point*)c->st_in.p);  // in place
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->st_in.p, (size_t)n * sizeof(o3dr_point), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return O3DR_OK;
+}
+
+// one stand-alone voxel grid over a device cloud -> device destination; returns count + status
+static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const float leaf[3], uint32_t min_points,
+                        float z_offset, o3dr_point* out_d, int64_t* n_out, uint32_t* status)
+{
+    CHK(ws_ensure(c, 1, n_in, false));
+    launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
+    launch_minmax_init(&c->prof, c->stream, c->ws.minmax, nullptr, 1);
+    launch_points_minmax(&c->prof, c->stream, in_d, 0, c->ws.n_valid, 1, n_in, c->ws.minmax);
+    CHK(zero_counters(c, c->cc_tmp));
+    VoxelArgs v;
+    v.in = in_d;
+    v.in_fstride = 0;
+    v.n_dev = c->ws.n_valid;
+    v.frames = 1;
+    v.cap = n_in;
+    v.leaf[0] = leaf[0];
+    v.leaf[1] = leaf[1];
+    v.leaf[2] = leaf[2];
+    v.min_points = min_points;
+    v.z_offset = z_offset;
+    v.out_base = out_d;
+    v.cc = c->cc_tmp;
+    v.passthrough = 0;
+    launch_voxel_grid(&c->prof, c->stream, c->ws, v);
+    HIPCHK(hipGetLastError());
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_tmp, &cc));
+    *n_out = (int64_t)cc.count;
+    if (status) *status = cc.status;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_voxel_grid(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, const float leaf[3], uint32_t min_points,
+                               float z_offset, o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
+                               int32_t mem)
+{
+    if (n_out) *n_out = 0;
+    if (status) *status = 0;
+    CTX_ENTER(c);
+    if (!n_out || n_in < 0 || !leaf || (n_in > 0 && (!in || !out))) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    if (!(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0)) return fail(O3DR_ERR_INVALID_ARG, "leaf must be positive");
+    if (n_in >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "more than 2^32-1 points in one cloud");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (n_in == 0) return O3DR_OK;
+    if (out_capacity < n_in && mem == O3DR_MEM_DEVICE)
+        return fail(O3DR_ERR_CAPACITY, "device output must hold n_in points (overflow fallback returns the input)");
+    const void* in_d;
+    CHK(stage_in(c, c->st_in, in, (size_t)n_in * sizeof(o3dr_point), mem, &in_d));
+    o3dr_point* out_d = out;
+    if (mem == O3DR_MEM_HOST) {
+        CHK(dev_ensure(c, c->st_out, (size_t)n_in * sizeof(o3dr_point)));
+        out_d = (o3dr_point*)c->st_out.p;
+    }
+    int64_t m = 0;
+    uint32_t st = 0;
+    CHK(voxel_single(c, (const o3dr_point*)in_d, n_in, leaf, min_points, z_offset, out_d, &m, &st));
+    if (mem == O3DR_MEM_HOST) {
+        if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+        if (m > 0) {
+            HIPCHK(hipMemcpyAsync(out, out_d, (size_t)m * sizeof(o3dr_point), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    }
+    *n_out = m;
+    if (status) *status = st;
+    return O3DR_OK;
+}
+
+static void downsample_leaf(const o3dr_params& p, int combined, float leaf[3], uint32_t* min_pts, float* z_offset)
+{
+    if (combined) {  // pose_functions.cpp:1666,1693-1694
+        leaf[0] = leaf[1] = (float)p.voxel_size;
+        leaf[2] = 1000.f;
+        *min_pts = p.min_points_per_voxel;
+        *z_offset = 500.f;
+    } else {  // :1698
+        leaf[0] = leaf[1] = leaf[2] = (float)(p.voxel_size / 5);
+        *min_pts = 0;
+        *z_offset = 0.f;
+    }
+}
+
+extern "C" int o3dr_downsample_pt_cloud(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, int32_t combined,
+                                        o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
+                                        int32_t mem)
+{
+    if (!c) {
+        if (n_out) *n_out = 0;
+        return fail(O3DR_ERR_INVALID_ARG, "ctx is NULL");
+    }
+    float leaf[3], zo;
+    uint32_t mp;
+    downsample_leaf(c->params, combined, leaf, &mp, &zo);
+    return o3dr_voxel_grid(c, in, n_in, leaf, mp, zo, out, out_capacity, n_out, status, mem);
+}
+
+// -------------------------------------------------------------------------------------------------
+// A7: device-resident accumulation
+// -------------------------------------------------------------------------------------------------
+static int cloud_reserve(o3dr_ctx* c, int64_t need)
+{
+    if (need <= c->cloud_cap) return O3DR_OK;
+    int64_t want = c->cloud_cap * 2;
+    if (want < need) want = need;
+    o3dr_point* nb = nullptr;
+    if (hipMalloc((void**)&nb, (size_t)want * sizeof(o3dr_point)) != hipSuccess) {
+        (void)hipGetLastError();
+        want = need;
+        if (hipMalloc((void**)&nb, (size_t)want * sizeof(o3dr_point)) != hipSuccess)
+            return fail(O3DR_ERR_ALLOC, "hipMalloc failed (cloud_big)");
+    }
+    if (c->cloud_big) {
+        CloudCounters cc;
+        CHK(read_counters(c, c->cc_big, &cc));
+        if (cc.count)
+            HIPCHK(hipMemcpyAsync(nb, c->cloud_big, (size_t)cc.count * sizeof(o3dr_point), hipMemcpyDeviceToDevice,
+                                  c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->cloud_big));
+        c->cloud_ub = (int64_t)cc.count;
+    }
+    c->cloud_big = nb;
+    c->cloud_cap = want;
+    return O3DR_OK;
+}
+
+// make room for `extra` more points; tightens the host-side bound with one sync when it must
+static int cloud_make_room(o3dr_ctx* c, int64_t extra)
+{
+    if (c->cloud_ub + extra > c->cloud_cap) {
+        CloudCounters cc;
+        CHK(read_counters(c, c->cc_big, &cc));
+        c->cloud_ub = (int64_t)cc.count;
+        if (c->cloud_ub + extra > c->cloud_cap) CHK(cloud_reserve(c, c->cloud_ub + extra));
+    }
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_reserve(o3dr_ctx* c, int64_t n_points)
+{
+    CTX_ENTER(c);
+    if (n_points < 0) return fail(O3DR_ERR_INVALID_ARG, "negative size");
+    return cloud_reserve(c, n_points);
+}
+
+extern "C" int o3dr_cloud_big_reset(o3dr_ctx* c)
+{
+    CTX_ENTER(c);
+    CHK(zero_counters(c, c->cc_big));
+    c->cloud_ub = 0;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_size(o3dr_ctx* c, int64_t* n, uint32_t* status)
+{
+    if (n) *n = 0;
+    CTX_ENTER(c);
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_big, &cc));
+    c->cloud_ub = (int64_t)cc.count;
+    if (n) *n = (int64_t)cc.count;
+    if (status) *status = cc.status;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_read(o3dr_ctx* c, o3dr_point* out, int64_t out_capacity, int64_t* n_out, int32_t mem)
+{
+    if (n_out) *n_out = 0;
+    CTX_ENTER(c);
+    if (!n_out) return fail(O3DR_ERR_INVALID_ARG, "n_out is NULL");
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_big, &cc));
+    const int64_t n = (int64_t)cc.count;
+    if (n > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+    if (n > 0) {
+        if (!out) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
+        HIPCHK(hipMemcpyAsync(out, c->cloud_big, (size_t)n * sizeof(o3dr_point),
+                              mem == O3DR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *n_out = n;
+    return O3DR_OK;
+}
+
+// appends n points and bumps the device counter (passthrough voxel job with a known count)
+extern "C" int o3dr_cloud_big_append(o3dr_ctx* c, const o3dr_point* pts, int64_t n, int32_t mem)
+{
+    CTX_ENTER(c);
+    if (n < 0 || (n > 0 && !pts)) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    if (n == 0) return O3DR_OK;
+    if (n >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "more than 2^32-1 points in one append");
+    CHK(cloud_make_room(c, n));
+    const void* src;
+    CHK(stage_in(c, c->st_in, pts, (size_t)n * sizeof(o3dr_point), mem, &src));
+    CHK(ws_ensure(c, 1, 1, false));
+    launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n, 1);
+    VoxelArgs v;
+    memset(&v, 0, sizeof v);
+    v.in = (const o3dr_point*)src;
+    v.n_dev = c->ws.n_valid;
+    v.frames = 1;
+    v.cap = n;
+    v.leaf[0] = v.leaf[1] = v.leaf[2] = 1.f;
+    v.out_base = c->cloud_big;
+    v.cc = c->cc_big;
+    v.passthrough = 1;
+    launch_minmax_init(&c->prof, c->stream, c->ws.minmax, nullptr, 1);
+    launch_voxel_grid(&c->prof, c->stream, c->ws, v);
+    HIPCHK(hipGetLastError());
+    c->cloud_ub += n;
+    if (mem == O3DR_MEM_HOST) HIPCHK(hipStreamSynchronize(c->stream));
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_transform(o3dr_ctx* c, const float T[16])
+{
+    CTX_ENTER(c);
+    if (!T) return fail(O3DR_ERR_INVALID_ARG, "T is NULL");
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_big, &cc));
+    launch_transform(&c->prof, c->stream, c->cloud_big, (int64_t)cc.count, T, c->cloud_big);
+    HIPCHK(hipGetLastError());
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
+                                      const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch, int32_t rows,
+                                      int32_t cols, const float* poses, int32_t n_frames, int32_t mem)
+{
+    CTX_ENTER(c);
+    if (!c->has_Q) return fail(O3DR_ERR_NOT_CONFIGURED, "o3dr_set_camera has not been called");
+    if (n_frames < 0 || (n_frames > 0 && !poses)) return fail(O3DR_ERR_INVALID_ARG, "bad frame list");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (n_frames == 0) return O3DR_OK;
+    CHK(check_images(disp, disp_pitch, bgr, bgr_pitch, rows, cols));
+    if (disp_frame_stride < (int64_t)rows * disp_pitch || bgr_frame_stride < (int64_t)rows * bgr_pitch)
+        return fail(O3DR_ERR_INVALID_ARG, "frame stride smaller than a frame");
+    const GridShape g = grid_shape(c->params, rows, cols);
+    if (g.n == 0) return O3DR_OK;  // jump_pixels == 0 without keypoints: nothing to add
+    const int B = n_frames < c->max_batch ? n_frames : c->max_batch;
+    CHK(ws_ensure(c, B, g.n, true));
+    float leaf[3], zo;
+    uint32_t mp;
+    downsample_leaf(c->params, 0, leaf, &mp, &zo);
+
+    for (int f0 = 0; f0 < n_frames; f0 += B) {
+        const int nb = (n_frames - f0) < B ? (n_frames - f0) : B;
+        CHK(cloud_make_room(c, (int64_t)nb * g.n));
+        const void *disp_d, *bgr_d, *poses_d;
+        CHK(stage_in(c, c->st_disp, disp + (int64_t)f0 * disp_frame_stride, (size_t)nb * disp_frame_stride, mem, &disp_d));
+        CHK(stage_in(c, c->st_bgr, bgr + (int64_t)f0 * bgr_frame_stride, (size_t)nb * bgr_frame_stride, mem, &bgr_d));
+        CHK(stage_in(c, c->st_poses, poses + 16 * (int64_t)f0, (size_t)nb * 16 * sizeof(float), mem, &poses_d));
+        ReprojectArgs a;
+        fill_args(c, a, (const uint8_t*)disp_d, disp_pitch, disp_frame_stride, (const uint8_t*)bgr_d, bgr_pitch,
+                  bgr_frame_stride, rows, cols, g, g.n);
+        a.xf_mode = 2;
+        a.poses = (const float*)poses_d;
+        launch_minmax_init(&c->prof, c->stream, c->ws.minmax, c->ws.n_kp, nb);
+        launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.minmax);
+        VoxelArgs v;
+        v.in = c->ws.pts;
+        v.in_fstride = g.n;
+        v.n_dev = c->ws.n_valid;
+        v.frames = nb;
+        v.cap = g.n;
+        v.leaf[0] = leaf[0];
+        v.leaf[1] = leaf[1];
+        v.leaf[2] = leaf[2];
+        v.min_points = mp;
+        v.z_offset = zo;
+        v.out_base = c->cloud_big;
+        v.cc = c->cc_big;
+        v.passthrough = c->params.dont_downsample ? 1 : 0;
+        launch_voxel_grid(&c->prof, c->stream, c->ws, v);
+        HIPCHK(hipGetLastError());
+        c->cloud_ub += (int64_t)nb * g.n;
+        if (mem == O3DR_MEM_HOST) HIPCHK(hipStreamSynchronize(c->stream));  // staging buffers are reused
+    }
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_finalize(o3dr_ctx* c, o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
+                             int32_t mem)
+{
+    if (n_out) *n_out = 0;
+    if (status) *status = 0;
+    CTX_ENTER(c);
+    if (!n_out) return fail(O3DR_ERR_INVALID_ARG, "n_out is NULL");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_big, &cc));
+    const int64_t n = (int64_t)cc.count;
+    c->cloud_ub = n;
+    if (n == 0) return O3DR_OK;
+    if (n >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+    if (!out) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
+    if (c->params.dont_downsample) {  // pose.cpp:534-537: cloud_small = cloud_big
+        if (n > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+        return o3dr_cloud_big_read(c, out, out_capacity, n_out, mem);
+    }
+    float leaf[3], zo;
+    uint32_t mp;
+    downsample_leaf(c->params, 1, leaf, &mp, &zo);
+    o3dr_point* out_d = out;
+    if (mem == O3DR_MEM_HOST) {
+        CHK(dev_ensure(c, c->st_out, (size_t)n * sizeof(o3dr_point)));
+        out_d = (o3dr_point*)c->st_out.p;
+    } else if (out_capacity < n) {
+        return fail(O3DR_ERR_CAPACITY, "device output must hold cloud_big (overflow fallback returns the input)");
+    }
+    int64_t m = 0;
+    uint32_t st = 0;
+    CHK(voxel_single(c, c->cloud_big, n, leaf, mp, zo, out_d, &m, &st));
+    if (mem == O3DR_MEM_HOST) {
+        if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+        if (m > 0) {
+            HIPCHK(hipMemcpyAsync(out, out_d, (size_t)m * sizeof(o3dr_point), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    }
+    *n_out = m;
+    if (status) *status = st | cc.status;
+    return O3DR_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// measurement hooks
+// -------------------------------------------------------------------------------------------------
+extern "C" int o3dr_profile_enable(o3dr_ctx* c, int32_t kernel_id, int32_t enable)
+{
+    CTX_ENTER(c);
+    if (kernel_id >= O3DR_K_NUM) return fail(O3DR_ERR_INVALID_ARG, "bad kernel id");
+    const uint32_t bits = kernel_id < 0 ? ((1u << O3DR_K_NUM) - 1u) : (1u << kernel_id);
+    if (enable)
+        c->prof.mask |= bits;
+    else
+        c->prof.mask &= ~bits;
+    return O3DR_OK;
+}
+extern "C" int o3dr_profile_read(o3dr_ctx* c, int32_t kernel_id, double* total_ms, int64_t* launches)
+{
+    CTX_ENTER(c);
+    if (kernel_id < 0 || kernel_id >= O3DR_K_NUM) return fail(O3DR_ERR_INVALID_ARG, "bad kernel id");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->prof.drain();
+    if (total_ms) *total_ms = c->prof.total_ms[kernel_id];
+    if (launches) *launches = c->prof.launches[kernel_id];
+    return O3DR_OK;
+}
+extern "C" int o3dr_profile_reset(o3dr_ctx* c)
+{
+    CTX_ENTER(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->prof.reset();
+    return O3DR_OK;
+}
+extern "C" int o3dr_device_info(o3dr_ctx* c, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes)
+{
+    CTX_ENTER(c);
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, c->device));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return O3DR_OK;
+}

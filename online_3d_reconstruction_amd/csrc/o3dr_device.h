@@ -1,0 +1,116 @@
+// o3dr_device.h — device-side data structures and kernel launchers shared by the C-ABI layer.
+// gfx950 only (64-wide wavefronts are assumed throughout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/o3dr.h"
+
+namespace o3dr {
+
+// ---- tiling constants -------------------------------------------------------------------------
+constexpr int kWave = 64;
+// reprojection: one 256-thread workgroup covers 1024 grid-pass candidates (4 per lane)
+constexpr int kEmitThreads = 256;
+constexpr int kEmitPerLane = 4;
+constexpr int kEmitTile = kEmitThreads * kEmitPerLane;
+// radix sort: 8 waves x 16 rounds x 64 lanes = 8192 keys per workgroup, 8-bit digits
+constexpr int kSortWaves = 8;
+constexpr int kSortThreads = kSortWaves * kWave;
+constexpr int kSortRounds = 16;
+constexpr int kSortWaveItems = kSortRounds * kWave;
+constexpr int kSortTile = kSortWaves * kSortWaveItems;
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+// generic per-point kernels
+constexpr int kPtThreads = 256;
+constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head kernels
+
+// ---- per-frame voxel grid geometry (PCL VoxelGrid members), written by k_voxel_geom -----------
+struct VoxelGeom {
+    float inv[3];       // inverse_leaf_size_
+    int32_t min_b[3];   // min_b_
+    int32_t div_b[3];   // div_b_
+    uint32_t mul1, mul2;  // divb_mul_[1], divb_mul_[2]
+    uint32_t overflow;    // dx*dy*dz > INT32_MAX  -> output = input
+    uint32_t n;           // points in this frame
+};
+
+// ---- arguments of the fused reprojection kernels (A1 + A2) ------------------------------------
+struct ReprojectArgs {
+    const uint8_t* disp;  // frame f at disp + f*disp_fstride
+    const uint8_t* bgr;
+    int64_t disp_pitch, bgr_pitch, disp_fstride, bgr_fstride;
+    const float* poses;   // xf_mode 2: 16 floats per frame (row-major) in HBM
+    int32_t xf_mode;      // 0: camera frame (A1 only); 1: T below (single frame); 2: poses[f]
+    float T[12];          // top three rows of the 4x4 pose, row-major
+    int32_t rows, cols, bb, cs, jump;
+    int32_t Ny, Nx;       // grid-pass extent
+    int32_t n_tiles;      // ceil(Ny*Nx / kEmitTile)
+    int32_t vec4;         // 1: jump==1, Nx%4==0, cs%4==0, pitches%4==0 -> packed 4-pixel loads
+    double Q[16];
+    double min_disp;
+    int64_t out_fstride;  // points between consecutive frames' output regions
+};
+
+// All per-batch device buffers.  Sizes are for `frames` frames of at most `cap` points each.
+struct Workspace {
+    int32_t frames = 0;
+    int64_t cap = 0;
+    int32_t n_emit_tiles = 0, n_sort_tiles = 0, n_seg_tiles = 0;
+    o3dr_point* pts = nullptr;     // frames*cap       transformed points (A1+A2 output)
+    uint32_t* keys[2] = {nullptr, nullptr};  // frames*cap ping-pong
+    uint32_t* vals[2] = {nullptr, nullptr};  // frames*cap ping-pong
+    uint32_t* seg_start = nullptr; // frames*(cap+1)   start of each voxel run in the sorted order
+    uint32_t* tile_cnt = nullptr;  // frames*n_emit_tiles
+    uint32_t* hist = nullptr;      // frames*kRadix*n_sort_tiles
+    uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
+    uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
+    uint32_t* minmax = nullptr;    // frames*6   order-preserving uint encoding of fp32 min/max
+    uint32_t* n_valid = nullptr;   // frames     points per frame after A1
+    uint32_t* n_kp = nullptr;      // frames     keypoint-pass points (single-frame API), else 0
+    uint32_t* n_vox = nullptr;     // frames     voxel runs
+    uint32_t* n_out = nullptr;     // frames     output points (kept runs, or n_valid on overflow)
+    uint64_t* out_off = nullptr;   // frames     absolute output offset of each frame
+    VoxelGeom* geom = nullptr;     // frames
+    size_t bytes = 0;
+};
+
+// device-resident counters of the accumulating cloud
+struct CloudCounters {
+    uint64_t count;     // points in cloud_big / in the current output buffer
+    uint32_t status;    // OR of O3DR_STATUS_* bits
+    uint32_t pad;
+};
+
+// ---- launchers (o3dr_kernels.hip).  All are asynchronous on `s`. -------------------------------
+struct Profiler;  // o3dr_api.hip
+
+void launch_minmax_init(Profiler* pf, hipStream_t s, uint32_t* minmax, uint32_t* n_kp, int frames);
+void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,
+                          o3dr_point* out, uint32_t* n_kp_out, uint32_t* minmax);
+void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
+                      uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, uint32_t* minmax);
+void launch_transform(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t n, const float* T16_host,
+                      o3dr_point* out);
+void launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
+                          const uint32_t* n_dev, int frames, int64_t cap, uint32_t* minmax);
+// voxel grid over `frames` independent clouds (cloud f = in + f*in_fstride, n_dev[f] points);
+// results are appended at out_base[cc->count + ...] in frame order and cc->count is advanced.
+struct VoxelArgs {
+    const o3dr_point* in;
+    int64_t in_fstride;
+    const uint32_t* n_dev;
+    int frames;
+    int64_t cap;
+    float leaf[3];
+    uint32_t min_points;
+    float z_offset;
+    o3dr_point* out_base;
+    CloudCounters* cc;
+    int passthrough;  // dont_downsample: append the input unchanged
+};
+void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
+void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);
+
+}  // namespace o3dr

@@ -1,0 +1,931 @@
+// o3dr_kernels.hip — hand-written gfx950 kernels of the reconstruction hot path.
+//
+//   K1  k_reproject_count / k_reproject_emit   A1+A2: (u,v,disparity) -> Q -> SE(3) -> ordered cloud
+//   K2  k_voxel_geom / k_voxel_keys            A4 steps 1-5: PCL VoxelGrid geometry and linear index
+//       k_radix_hist / k_radix_scatter         A4 step 6: stable LSD radix sort of (index, point id)
+//       k_run_heads / k_run_starts / k_centroid  A4 steps 7-8: runs -> ordered fp32 centroid
+//
+// Everything here is HBM-bound integer/byte/fp32 work: no MFMA.  The whole translation unit is
+// compiled with -ffp-contract=off because the reference arithmetic (unoptimised x86 build,
+// SURVEY.md section 7 "hard parts") never fuses a multiply-add, and a 1-ulp difference in a world
+// coordinate flips voxel occupancy.
+//
+// Reference lines each kernel follows are cited at the kernel.  Wavefront size is 64.
+#include "o3dr_device.h"
+#include "o3dr_profile.h"
+
+namespace o3dr {
+
+// =================================================================================================
+// small device helpers
+// =================================================================================================
+__device__ __forceinline__ uint32_t f32_ordered(float f)
+{  // order-preserving map fp32 -> uint32 (for atomicMin/atomicMax)
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_f32(uint32_t e)
+{
+    const uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+// exclusive scan of one value per thread over a workgroup of NW waves; returns the exclusive
+// prefix, `total` = sum over the workgroup.  `lds` holds NW+1 words.
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* lds, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(v);
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t t = lds[i];
+            lds[i] = run;
+            run += t;
+        }
+        lds[NW] = run;
+    }
+    __syncthreads();
+    const uint32_t r = lds[w] + incl - v;
+    total = lds[NW];
+    __syncthreads();
+    return r;
+}
+// workgroup min/max of per-thread (lo[3], hi[3]) -> atomics on the frame's ordered-uint slots
+template <int NW>
+__device__ __forceinline__ void block_minmax_atomic(const float lo[3], const float hi[3], bool any,
+                                                    float* lds /*6*NW*/, uint32_t* mm6)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_min_f32(any ? lo[a] : __builtin_inff());
+        const float h = wave_max_f32(any ? hi[a] : -__builtin_inff());
+        if (lane == 0) {
+            lds[w * 6 + a] = l;
+            lds[w * 6 + 3 + a] = h;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float v = lds[a];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) v = (a < 3) ? fminf(v, lds[i * 6 + a]) : fmaxf(v, lds[i * 6 + a]);
+        if (a < 3) {
+            if (v != __builtin_inff()) atomicMin(&mm6[a], f32_ordered(v));
+        } else {
+            if (v != -__builtin_inff()) atomicMax(&mm6[a], f32_ordered(v));
+        }
+    }
+    __syncthreads();
+}
+
+// =================================================================================================
+// K1 — fused reprojection + rigid transform (A1 + A2)
+//
+//   pose_functions.cpp:1110-1121: vec = Q*(x,y,d,1) in fp64 (rows evaluated left to right),
+//       vec /= vec(3) as multiplication by 1./vec(3) (+0), (float) casts, colour R<<16|G<<8|B;
+//   pose_functions.cpp:1358-1362 -> pcl::transformPointCloud, dense branch:
+//       x' = ((m00*x + m01*y) + m02*z) + m03 in fp32, no fused multiply-add.
+// =================================================================================================
+struct Pix {
+    float x, y, z;
+    uint32_t rgba;
+};
+
+__device__ __forceinline__ Pix reproject_one(const double* __restrict__ Q, int x, int y, double d,
+                                             uint32_t b, uint32_t g, uint32_t r, const float* m, bool xf)
+{
+    const double v0 = (double)x, v1 = (double)y;
+    const double t0 = ((Q[0] * v0 + Q[1] * v1) + Q[2] * d) + Q[3];
+    const double t1 = ((Q[4] * v0 + Q[5] * v1) + Q[6] * d) + Q[7];
+    const double t2 = ((Q[8] * v0 + Q[9] * v1) + Q[10] * d) + Q[11];
+    const double t3 = ((Q[12] * v0 + Q[13] * v1) + Q[14] * d) + Q[15];
+    const double alpha = 1. / t3;
+    const float X = (float)(t0 * alpha + 0.0);
+    const float Y = (float)(t1 * alpha + 0.0);
+    const float Z = (float)(t2 * alpha + 0.0);
+    Pix p;
+    if (xf) {
+        p.x = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+        p.y = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+        p.z = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+    } else {
+        p.x = X;
+        p.y = Y;
+        p.z = Z;
+    }
+    p.rgba = (r << 16) | (g << 8) | b;
+    return p;
+}
+
+// disparity bytes of the (up to) 4 candidates of one lane; returns the validity mask
+__device__ __forceinline__ uint32_t load_lane_disparities(const ReprojectArgs& a, const uint8_t* __restrict__ disp,
+                                                          int c0, int n_cand, int& x0, int& y0, uint32_t d[4])
+{
+    uint32_t valid = 0;
+    if (c0 >= n_cand) return 0;
+    if (a.vec4) {  // 4 consecutive pixels of one row, 4-byte aligned
+        const int ry = c0 / a.Nx, rx = c0 - ry * a.Nx;
+        y0 = a.bb + ry;
+        x0 = a.cs + rx;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(disp + (int64_t)y0 * a.disp_pitch + x0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d[k] = (w >> (8 * k)) & 255u;
+            if ((double)d[k] > a.min_disp) valid |= 1u << k;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            d[k] = 0;
+            if (c < n_cand) {
+                const int ry = c / a.Nx, rx = c - ry * a.Nx;
+                d[k] = disp[(int64_t)(a.bb + ry * a.jump) * a.disp_pitch + (a.cs + rx * a.jump)];
+                if ((double)d[k] > a.min_disp) valid |= 1u << k;
+            }
+        }
+    }
+    return valid;
+}
+
+// pass 1: valid candidates per 1024-candidate tile (reads 1 byte per candidate)
+__global__ __launch_bounds__(kEmitThreads) void k_reproject_count(ReprojectArgs a, uint32_t* __restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[kEmitThreads / 64];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const uint8_t* disp = a.disp + (int64_t)f * a.disp_fstride;
+    const int n_cand = a.Ny * a.Nx;
+    const int c0 = tile * kEmitTile + threadIdx.x * kEmitPerLane;
+    int x0 = 0, y0 = 0;
+    uint32_t d[4];
+    const uint32_t valid = load_lane_disparities(a, disp, c0, n_cand, x0, y0, d);
+    const uint32_t s = wave_sum_u32(__popc(valid));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < kEmitThreads / 64; ++i) t += lds[i];
+        tile_cnt[(int64_t)f * a.n_tiles + tile] = t;
+    }
+}
+
+// pass 2: recompute, transform, compact in row-major order, write 16-byte points coalesced
+__global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a, o3dr_point* __restrict__ out,
+                                                                 const uint32_t* __restrict__ tile_off,
+                                                                 const uint32_t* __restrict__ n_kp,
+                                                                 uint32_t* __restrict__ minmax)
+{
+    __shared__ uint4 stage[kEmitTile];  // 16 KiB: the tile's points in output order
+    __shared__ uint32_t scan_lds[kEmitThreads / 64 + 1];
+    __shared__ float mm_lds[6 * (kEmitThreads / 64)];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const uint8_t* disp = a.disp + (int64_t)f * a.disp_fstride;
+    const uint8_t* bgr = a.bgr + (int64_t)f * a.bgr_fstride;
+    const int n_cand = a.Ny * a.Nx;
+    const int c0 = tile * kEmitTile + threadIdx.x * kEmitPerLane;
+
+    float m[12];
+    const bool xf = a.xf_mode != 0;
+    if (a.xf_mode == 2) {
+        const float* T = a.poses + 16 * (int64_t)f;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int i = 0; i < 12; ++i) m[i] = T[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) m[i] = a.T[i];
+    }
+
+    int x0 = 0, y0 = 0;
+    uint32_t d[4];
+    const uint32_t valid = load_lane_disparities(a, disp, c0, n_cand, x0, y0, d);
+
+    Pix p[4];
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    if (valid) {
+        uint32_t cb[4], cg[4], cr[4];
+        if (a.vec4) {  // 12 colour bytes of 4 pixels = 3 aligned dwords
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(bgr + (int64_t)y0 * a.bgr_pitch + 3 * (int64_t)x0);
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+            cb[0] = w0 & 255u;         cg[0] = (w0 >> 8) & 255u;  cr[0] = (w0 >> 16) & 255u;
+            cb[1] = w0 >> 24;          cg[1] = w1 & 255u;         cr[1] = (w1 >> 8) & 255u;
+            cb[2] = (w1 >> 16) & 255u; cg[2] = w1 >> 24;          cr[2] = w2 & 255u;
+            cb[3] = (w2 >> 8) & 255u;  cg[3] = (w2 >> 16) & 255u; cr[3] = w2 >> 24;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (valid & (1u << k)) {
+                int x, y;
+                if (a.vec4) {
+                    x = x0 + k;
+                    y = y0;
+                } else {
+                    const int c = c0 + k;
+                    const int ry = c / a.Nx, rx = c - ry * a.Nx;
+                    y = a.bb + ry * a.jump;
+                    x = a.cs + rx * a.jump;
+                    const uint8_t* px = bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
+                    cb[k] = px[0];
+                    cg[k] = px[1];
+                    cr[k] = px[2];
+                }
+                p[k] = reproject_one(a.Q, x, y, (double)d[k], cb[k], cg[k], cr[k], m, xf);
+                lo[0] = fminf(lo[0], p[k].x); hi[0] = fmaxf(hi[0], p[k].x);
+                lo[1] = fminf(lo[1], p[k].y); hi[1] = fmaxf(hi[1], p[k].y);
+                lo[2] = fminf(lo[2], p[k].z); hi[2] = fmaxf(hi[2], p[k].z);
+            }
+        }
+    }
+    uint32_t total;
+    uint32_t pos = block_excl_scan_u32<kEmitThreads / 64>(__popc(valid), scan_lds, total);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (valid & (1u << k)) {
+            stage[pos] = make_uint4(__float_as_uint(p[k].x), __float_as_uint(p[k].y), __float_as_uint(p[k].z), p[k].rgba);
+            ++pos;
+        }
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(out + (int64_t)f * a.out_fstride + n_kp[f] + tile_off[(int64_t)f * a.n_tiles + tile]);
+    for (uint32_t i = threadIdx.x; i < total; i += kEmitThreads) dst[i] = stage[i];
+    block_minmax_atomic<kEmitThreads / 64>(lo, hi, valid != 0, mm_lds, minmax + 6 * f);
+}
+
+// keypoint pass (pose_functions.cpp:1057-1091): one workgroup walks the keypoints in order
+__global__ __launch_bounds__(256) void k_keypoint_pass(ReprojectArgs a, const float* __restrict__ kp_xy, int n_kp,
+                                                       o3dr_point* __restrict__ out, uint32_t* __restrict__ n_kp_out,
+                                                       uint32_t* __restrict__ minmax)
+{
+    __shared__ uint32_t scan_lds[256 / 64 + 1];
+    __shared__ float mm_lds[6 * 4];
+    float m[12];
+    const bool xf = a.xf_mode != 0;
+    for (int i = 0; i < 12; ++i) m[i] = (a.xf_mode == 2) ? a.poses[i] : a.T[i];
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    bool any = false;
+    uint32_t base = 0;
+    for (int i0 = 0; i0 < n_kp; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        bool ok = false;
+        Pix p;
+        if (i < n_kp) {
+            const int x = (int)kp_xy[2 * i], y = (int)kp_xy[2 * i + 1];
+            if (x >= a.cs && x < a.cols - a.bb && y >= a.bb && y < a.rows - a.bb) {
+                const uint32_t d = a.disp[(int64_t)y * a.disp_pitch + x];
+                if ((double)d > a.min_disp) {
+                    const uint8_t* px = a.bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
+                    p = reproject_one(a.Q, x, y, (double)d, px[0], px[1], px[2], m, xf);
+                    ok = true;
+                }
+            }
+        }
+        uint32_t total;
+        const uint32_t pos = block_excl_scan_u32<4>(ok ? 1u : 0u, scan_lds, total);
+        if (ok) {
+            o3dr_point q;
+            q.x = p.x; q.y = p.y; q.z = p.z; q.rgba = p.rgba;
+            out[base + pos] = q;
+            any = true;
+            lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+            lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+            lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) n_kp_out[0] = base;
+    block_minmax_atomic<4>(lo, hi, any, mm_lds, minmax);
+}
+
+// A2 alone: pcl::transformPointCloud on an existing cloud (also the in-place re-transform of
+// cloud_big, pose.cpp:353)
+struct Mat34 {
+    float m[12];
+};
+__global__ __launch_bounds__(kPtThreads) void k_transform(const o3dr_point* __restrict__ in, int64_t n, Mat34 T,
+                                                          o3dr_point* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+    const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z);
+    const float* m = T.m;
+    const float X = ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+    const float Y = ((m[4] * x + m[5] * y) + m[6] * z) + m[7];
+    const float Z = ((m[8] * x + m[9] * y) + m[10] * z) + m[11];
+    reinterpret_cast<uint4*>(out)[i] = make_uint4(__float_as_uint(X), __float_as_uint(Y), __float_as_uint(Z), v.w);
+}
+
+// =================================================================================================
+// small bookkeeping kernels
+// =================================================================================================
+__global__ void k_minmax_init(uint32_t* minmax, uint32_t* n_kp, int frames)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < frames * 6) minmax[i] = (i % 6 < 3) ? 0xffffffffu : 0u;
+    if (n_kp && i < frames) n_kp[i] = 0;
+}
+__global__ void k_set_counts(uint32_t* n_dev, uint32_t value, int frames)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < frames) n_dev[i] = value;
+}
+
+// Exclusive scan of `frames` independent rows of length L (row f at data + f*row_stride), in place.
+// One 1024-thread workgroup per row; each thread owns a contiguous chunk.  totals[f] (optional)
+// receives the row sum plus add[f] (optional).
+__global__ __launch_bounds__(1024) void k_scan_rows(uint32_t* __restrict__ data, int64_t L, int64_t row_stride,
+                                                    uint32_t* __restrict__ totals, const uint32_t* __restrict__ add)
+{
+    __shared__ uint32_t lds[1024 / 64 + 1];
+    uint32_t* row = data + (int64_t)blockIdx.x * row_stride;
+    const int64_t chunk = (L + 1023) / 1024;
+    const int64_t b = (int64_t)threadIdx.x * chunk;
+    const int64_t e = (b + chunk < L) ? b + chunk : L;
+    uint32_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += row[i];
+    uint32_t total;
+    uint32_t run = block_excl_scan_u32<16>(s, lds, total);
+    for (int64_t i = b; i < e; ++i) {
+        const uint32_t t = row[i];
+        row[i] = run;
+        run += t;
+    }
+    if (totals && threadIdx.x == 0) totals[blockIdx.x] = total + (add ? add[blockIdx.x] : 0u);
+}
+
+// fp32 min/max of arbitrary clouds (stand-alone voxel grid calls; the fused path gets its
+// bounding box from k_reproject_emit).  The `z += 500` of the combined mode (pose_functions.cpp:1666)
+// is applied to the box afterwards by k_voxel_geom: fp32 addition is monotonic.
+__global__ __launch_bounds__(kPtThreads) void k_points_minmax(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                              const uint32_t* __restrict__ n_dev,
+                                                              uint32_t* __restrict__ minmax)
+{
+    __shared__ float mm_lds[6 * (kPtThreads / 64)];
+    const int f = blockIdx.y;
+    const int64_t n = n_dev[f];
+    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    bool any = false;
+    const int64_t base = (int64_t)blockIdx.x * (kPtThreads * 8);
+    if (base >= n) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = base + k * kPtThreads + threadIdx.x;
+        if (i < n) {
+            const uint4 v = src[i];
+            const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z);
+            lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+            lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+            lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+            any = true;
+        }
+    }
+    block_minmax_atomic<kPtThreads / 64>(lo, hi, any, mm_lds, minmax + 6 * f);
+}
+
+// =================================================================================================
+// K2a — PCL VoxelGrid geometry and per-point linear index
+//   [PCL 1.8 filters/impl/voxel_grid.hpp applyFilter; called from pose_functions.cpp:1689-1700]
+// =================================================================================================
+__global__ void k_voxel_geom(const uint32_t* __restrict__ minmax, const uint32_t* __restrict__ n_dev, int frames,
+                             float leaf0, float leaf1, float leaf2, float z_offset,
+                             VoxelGeom* __restrict__ geom)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    VoxelGeom g;
+    const float leaf[3] = {leaf0, leaf1, leaf2};
+    g.n = n_dev[f];
+    g.overflow = 0;
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) {
+        g.inv[a] = 1.0f / leaf[a];  // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
+        mn[a] = ordered_f32(minmax[6 * f + a]);
+        mx[a] = ordered_f32(minmax[6 * f + 3 + a]);
+    }
+    // the bounding box was taken before `z += 500` (pose_functions.cpp:1666); fp32 add is monotonic
+    mn[2] = mn[2] + z_offset;
+    mx[2] = mx[2] + z_offset;
+    if (g.n == 0) {
+        for (int a = 0; a < 3; ++a) g.min_b[a] = 0, g.div_b[a] = 1;
+        g.mul1 = g.mul2 = 1;
+        geom[f] = g;
+        return;
+    }
+    // int64_t dx = static_cast<int64_t>((max_p[0]-min_p[0])*inverse_leaf_size_[0]) + 1; ...
+    int64_t d[3];
+    for (int a = 0; a < 3; ++a) d[a] = (int64_t)((mx[a] - mn[a]) * g.inv[a]) + 1;
+    g.overflow = (d[0] * d[1] * d[2]) > (int64_t)INT32_MAX ? 1u : 0u;
+    for (int a = 0; a < 3; ++a) {
+        g.min_b[a] = (int32_t)floorf(mn[a] * g.inv[a]);
+        const int32_t max_b = (int32_t)floorf(mx[a] * g.inv[a]);
+        g.div_b[a] = max_b - g.min_b[a] + 1;
+    }
+    g.mul1 = (uint32_t)g.div_b[0];
+    g.mul2 = (uint32_t)g.div_b[0] * (uint32_t)g.div_b[1];
+    geom[f] = g;
+}
+
+// idx = ijk0*divb_mul[0] + ijk1*divb_mul[1] + ijk2*divb_mul[2] with
+// ijk = int(floor(p*inverse_leaf) - float(min_b));  floor and subtraction are exact here, so the
+// difference is taken in integers.
+__global__ __launch_bounds__(kPtThreads) void k_voxel_keys(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                           const VoxelGeom* __restrict__ geom, float z_offset,
+                                                           int64_t cap, uint32_t* __restrict__ keys)
+{
+    const int f = blockIdx.y;
+    const VoxelGeom g = geom[f];
+    if (g.overflow) return;
+    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+    uint32_t* dst = keys + (int64_t)f * cap;
+    const int64_t base = (int64_t)blockIdx.x * (kPtThreads * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * kPtThreads + threadIdx.x;
+        if (i < g.n) {
+            const uint4 v = src[i];
+            const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z) + z_offset;
+            const int32_t i0 = (int32_t)floorf(x * g.inv[0]) - g.min_b[0];
+            const int32_t i1 = (int32_t)floorf(y * g.inv[1]) - g.min_b[1];
+            const int32_t i2 = (int32_t)floorf(z * g.inv[2]) - g.min_b[2];
+            dst[i] = (uint32_t)i0 + (uint32_t)i1 * g.mul1 + (uint32_t)i2 * g.mul2;
+        }
+    }
+}
+
+// =================================================================================================
+// K2b — stable LSD radix sort of (voxel index, point id), 8 bits per pass.
+//   PCL sorts with std::sort (order inside a voxel unspecified); the canonical order here is the
+//   stable one: points of a voxel stay in ascending input order.  A workgroup owns 8192 consecutive
+//   records, a wave 1024 of them, visited in 16 rounds of 64 lanes so that (round, lane) order is
+//   input order.  Ranks come from wave ballots (match-any on the digit) plus per-wave LDS counters.
+// =================================================================================================
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t cap,
+                                                             const VoxelGeom* __restrict__ geom, int shift,
+                                                             int n_tiles, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[kRadix];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = geom[f].n;
+    if (geom[f].overflow) return;
+    for (int i = threadIdx.x; i < kRadix; i += kSortThreads) h[i] = 0;
+    __syncthreads();
+    const uint32_t* src = keys + (int64_t)f * cap;
+    const int64_t base = (int64_t)tile * kSortTile;
+    if (base < n) {
+#pragma unroll 4
+        for (int r = 0; r < kSortRounds; ++r) {
+            const int64_t i = base + (int64_t)(threadIdx.x >> 6) * kSortWaveItems + r * kWave + (threadIdx.x & 63);
+            if (i < n) atomicAdd(&h[(src[i] >> shift) & (kRadix - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* dst = hist + (int64_t)f * kRadix * n_tiles;
+    for (int dgt = threadIdx.x; dgt < kRadix; dgt += kSortThreads) dst[(int64_t)dgt * n_tiles + tile] = h[dgt];
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in,
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, int64_t cap,
+                                                                const VoxelGeom* __restrict__ geom, int shift,
+                                                                int first_pass, int n_tiles,
+                                                                const uint32_t* __restrict__ hist_scanned)
+{
+    __shared__ uint32_t wave_cnt[kSortWaves * kRadix];  // 8 KiB
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const uint32_t n = geom[f].n;
+    if (geom[f].overflow) return;
+    const int64_t base = (int64_t)tile * kSortTile;
+    if (base >= n) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t* kin = keys_in + (int64_t)f * cap;
+    const uint32_t* vin = vals_in + (int64_t)f * cap;
+
+    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) wave_cnt[i] = 0;
+    __syncthreads();
+
+    uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
+    const int64_t wbase = base + (int64_t)w * kSortWaveItems;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = wbase + r * kWave + lane;
+        const bool ok = i < n;
+        key[r] = ok ? kin[i] : 0xffffffffu;
+        val[r] = first_pass ? (uint32_t)i : (ok ? vin[i] : 0u);
+    }
+    volatile uint32_t* wc = wave_cnt + w * kRadix;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = wbase + r * kWave + lane;
+        const bool ok = i < n;
+        const uint32_t dgt = (key[r] >> shift) & (kRadix - 1);
+        // lanes of this round holding the same digit
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const bool bit = (dgt >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        uint32_t prior = 0;
+        if (ok) prior = wc[dgt];
+        rank[r] = prior + (uint32_t)__popcll(peers & lt_mask);
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (peers & lt_mask) == 0) wc[dgt] = prior + (uint32_t)__popcll(peers);  // lowest peer updates
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // exclusive offsets: global start of (digit, tile) + counts of lower waves
+    const uint32_t* hs = hist_scanned + (int64_t)f * kRadix * n_tiles;
+    for (int dgt = threadIdx.x; dgt < kRadix; dgt += kSortThreads) {
+        uint32_t run = hs[(int64_t)dgt * n_tiles + tile];
+#pragma unroll
+        for (int ww = 0; ww < kSortWaves; ++ww) {
+            const uint32_t t = wave_cnt[ww * kRadix + dgt];
+            wave_cnt[ww * kRadix + dgt] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    uint32_t* kout = keys_out + (int64_t)f * cap;
+    uint32_t* vout = vals_out + (int64_t)f * cap;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = wbase + r * kWave + lane;
+        if (i < n) {
+            const uint32_t dgt = (key[r] >> shift) & (kRadix - 1);
+            const uint32_t dstpos = wave_cnt[w * kRadix + dgt] + rank[r];
+            kout[dstpos] = key[r];
+            vout[dstpos] = val[r];
+        }
+    }
+}
+
+// =================================================================================================
+// K2c — runs of equal index -> one output point each
+//   third/fourth pass of VoxelGrid::applyFilter + CentroidPoint<PointXYZRGB>
+//   [PCL 1.8 common/impl/accumulators.hpp: fp32 sums, xyz / n, uint32_t(channel / n)]
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ keys, int64_t cap,
+                                                   const VoxelGeom* __restrict__ geom, int n_tiles,
+                                                   uint32_t* __restrict__ seg_cnt)
+{
+    __shared__ uint32_t lds[4];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    if (geom[f].overflow) return;
+    const uint32_t n = geom[f].n;
+    const uint32_t* k = keys + (int64_t)f * cap;
+    uint32_t c = 0;
+    const int64_t base = (int64_t)tile * kSegTile;
+    if (base < n) {
+#pragma unroll
+        for (int j = 0; j < kSegTile / 256; ++j) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            if (i < n) c += (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
+        }
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[(int64_t)f * n_tiles + tile] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__ keys, int64_t cap,
+                                                    const VoxelGeom* __restrict__ geom, int n_tiles,
+                                                    const uint32_t* __restrict__ seg_off,
+                                                    const uint32_t* __restrict__ n_vox,
+                                                    uint32_t* __restrict__ seg_start)
+{
+    __shared__ uint32_t scan_lds[5];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    if (geom[f].overflow) return;
+    const uint32_t n = geom[f].n;
+    const int64_t base = (int64_t)tile * kSegTile;
+    if (base >= n) return;
+    const uint32_t* k = keys + (int64_t)f * cap;
+    uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+    if (tile == 0 && threadIdx.x == 0) ss[n_vox[f]] = n;  // sentinel: end of the last run
+    uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
+    // 4 sub-rows of 256 consecutive records keep (sub-row, lane) order = sorted order
+    for (int j = 0; j < kSegTile / 256; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const bool head = (i < n) && (i == 0 || k[i] != k[i - 1]);
+        uint32_t total;
+        const uint32_t pos = block_excl_scan_u32<4>(head ? 1u : 0u, scan_lds, total);
+        if (head) ss[off + pos] = (uint32_t)i;
+        off += total;
+    }
+}
+
+// min_points_per_voxel > 1 (combined merge, pose_functions.cpp:1693): runs with fewer points are dropped
+__global__ __launch_bounds__(256) void k_keep_count(const uint32_t* __restrict__ seg_start, int64_t cap,
+                                                    const VoxelGeom* __restrict__ geom,
+                                                    const uint32_t* __restrict__ n_vox, uint32_t min_points,
+                                                    int n_tiles, uint32_t* __restrict__ seg_cnt)
+{
+    __shared__ uint32_t lds[4];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    if (geom[f].overflow) return;
+    const uint32_t nv = n_vox[f];
+    const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+    uint32_t c = 0;
+    const int64_t base = (int64_t)tile * kSegTile;
+    if (base < nv) {
+        for (int j = 0; j < kSegTile / 256; ++j) {
+            const int64_t o = base + j * 256 + threadIdx.x;
+            if (o < nv) c += (ss[o + 1] - ss[o] >= min_points) ? 1u : 0u;
+        }
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[(int64_t)f * n_tiles + tile] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+__global__ __launch_bounds__(256) void k_keep_write(const uint32_t* __restrict__ seg_start, int64_t cap,
+                                                    const VoxelGeom* __restrict__ geom,
+                                                    const uint32_t* __restrict__ n_vox, uint32_t min_points,
+                                                    int n_tiles, const uint32_t* __restrict__ seg_off,
+                                                    uint32_t* __restrict__ keep_idx)
+{
+    __shared__ uint32_t scan_lds[5];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    if (geom[f].overflow) return;
+    const uint32_t nv = n_vox[f];
+    const int64_t base = (int64_t)tile * kSegTile;
+    if (base >= nv) return;
+    const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+    uint32_t* ki = keep_idx + (int64_t)f * cap;
+    uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
+    for (int j = 0; j < kSegTile / 256; ++j) {
+        const int64_t o = base + j * 256 + threadIdx.x;
+        const bool keep = (o < nv) && (ss[o + 1] - ss[o] >= min_points);
+        uint32_t total;
+        const uint32_t pos = block_excl_scan_u32<4>(keep ? 1u : 0u, scan_lds, total);
+        if (keep) ki[off + pos] = (uint32_t)o;
+        off += total;
+    }
+}
+
+// per-frame output counts -> absolute offsets; advances the cloud counter (one thread: frames <= 64)
+__global__ void k_frame_offsets(const VoxelGeom* __restrict__ geom, const uint32_t* __restrict__ n_vox,
+                                const uint32_t* __restrict__ n_keep, int frames, int passthrough,
+                                uint32_t* __restrict__ n_out, uint64_t* __restrict__ out_off,
+                                CloudCounters* __restrict__ cc)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t run = cc->count;
+    uint32_t st = 0;
+    for (int f = 0; f < frames; ++f) {
+        uint32_t m;
+        if (passthrough) {
+            m = geom[f].n;
+        } else if (geom[f].overflow) {
+            m = geom[f].n;
+            st |= O3DR_STATUS_VOXEL_OVERFLOW;
+        } else {
+            m = n_keep ? n_keep[f] : n_vox[f];
+        }
+        n_out[f] = m;
+        out_off[f] = run;
+        run += m;
+    }
+    cc->count = run;
+    cc->status |= st;
+}
+
+__global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                         const uint32_t* __restrict__ vals, int64_t cap,
+                                                         const uint32_t* __restrict__ seg_start,
+                                                         const uint32_t* __restrict__ keep_idx,
+                                                         const VoxelGeom* __restrict__ geom,
+                                                         const uint32_t* __restrict__ n_out,
+                                                         const uint64_t* __restrict__ out_off, float z_offset,
+                                                         int passthrough, o3dr_point* __restrict__ out_base)
+{
+    const int f = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
+    if (o >= n_out[f]) return;
+    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+    uint4* dst = reinterpret_cast<uint4*>(out_base + out_off[f]);
+    if (passthrough) {
+        dst[o] = src[o];
+        return;
+    }
+    if (geom[f].overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
+        uint4 v = src[o];
+        v.z = __float_as_uint((__uint_as_float(v.z) + z_offset) - z_offset);
+        dst[o] = v;
+        return;
+    }
+    const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+    const uint32_t* pid = vals + (int64_t)f * cap;
+    const uint32_t v = keep_idx ? keep_idx[(int64_t)f * cap + o] : (uint32_t)o;
+    const uint32_t b = ss[v], e = ss[v + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
+    for (uint32_t li = b; li < e; ++li) {
+        const uint4 p = src[pid[li]];
+        sx += __uint_as_float(p.x);
+        sy += __uint_as_float(p.y);
+        sz += __uint_as_float(p.z) + z_offset;
+        sr += (float)((p.w >> 16) & 255u);
+        sg += (float)((p.w >> 8) & 255u);
+        sb += (float)(p.w & 255u);
+        sa += (float)(p.w >> 24);
+    }
+    const float nf = (float)(e - b);
+    const float cx = sx / nf, cy = sy / nf, cz = sz / nf - z_offset;
+    const uint32_t rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) | ((uint32_t)(sg / nf) << 8) |
+                          (uint32_t)(sb / nf);
+    dst[o] = make_uint4(__float_as_uint(cx), __float_as_uint(cy), __float_as_uint(cz), rgba);
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+void launch_minmax_init(Profiler* pf, hipStream_t s, uint32_t* minmax, uint32_t* n_kp, int frames)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_minmax_init<<<cdiv64(frames * 6, 256), 256, 0, s>>>(minmax, n_kp, frames);
+}
+
+void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_set_counts<<<cdiv64(frames, 256), 256, 0, s>>>(n_dev, value, frames);
+}
+
+void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,
+                          o3dr_point* out, uint32_t* n_kp_out, uint32_t* minmax)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_keypoint_pass<<<1, 256, 0, s>>>(a, kp_xy, n_kp, out, n_kp_out, minmax);
+}
+
+void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
+                      uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, uint32_t* minmax)
+{
+    if (a.n_tiles <= 0) {  // jump_pixels == 0: keypoints only
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        (void)hipMemcpyAsync(n_valid, n_kp, sizeof(uint32_t) * frames, hipMemcpyDeviceToDevice, s);
+        return;
+    }
+    const dim3 grid(a.n_tiles, frames);
+    {
+        ProfScope ps(pf, O3DR_K_COUNT, s);
+        k_reproject_count<<<grid, kEmitThreads, 0, s>>>(a, tile_cnt);
+    }
+    {
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        k_scan_rows<<<frames, 1024, 0, s>>>(tile_cnt, a.n_tiles, a.n_tiles, n_valid, n_kp);
+    }
+    {
+        ProfScope ps(pf, O3DR_K_REPROJECT, s);
+        k_reproject_emit<<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, minmax);
+    }
+}
+
+void launch_transform(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t n, const float* T16_host,
+                      o3dr_point* out)
+{
+    if (n <= 0) return;
+    Mat34 T;
+    for (int i = 0; i < 12; ++i) T.m[i] = T16_host[i];
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_transform<<<cdiv64(n, kPtThreads), kPtThreads, 0, s>>>(in, n, T, out);
+}
+
+void launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
+                          const uint32_t* n_dev, int frames, int64_t cap, uint32_t* minmax)
+{
+    if (cap <= 0) return;
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_points_minmax<<<dim3(cdiv64(cap, kPtThreads * 8), frames), kPtThreads, 0, s>>>(in, in_fstride, n_dev, minmax);
+}
+
+// The voxel grid proper.  Expects ws.minmax to hold the bounding boxes of the (un-offset) inputs.
+void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v)
+{
+    const int F = v.frames;
+    const int64_t cap = v.cap;
+    const int n_sort_tiles = cdiv64(cap, kSortTile);
+    const int n_seg_tiles = cdiv64(cap, kSegTile);
+    {
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        k_voxel_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.minmax, v.n_dev, F, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset,
+                                                 ws.geom);
+    }
+    uint32_t* n_keep = nullptr;
+    if (!v.passthrough && cap > 0) {
+        {
+            ProfScope ps(pf, O3DR_K_KEYGEN, s);
+            k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, ws.geom,
+                                                                                    v.z_offset, cap, ws.keys[0]);
+        }
+        int cur = 0;
+        for (int pass = 0; pass < 32 / kRadixBits; ++pass) {
+            const int shift = pass * kRadixBits;
+            const dim3 grid(n_sort_tiles, F);
+            {
+                ProfScope ps(pf, O3DR_K_SORT_HIST, s);
+                k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[cur], cap, ws.geom, shift, n_sort_tiles, ws.hist);
+            }
+            {
+                ProfScope ps(pf, O3DR_K_OTHER, s);
+                k_scan_rows<<<F, 1024, 0, s>>>(ws.hist, (int64_t)kRadix * n_sort_tiles, (int64_t)kRadix * n_sort_tiles,
+                                              nullptr, nullptr);
+            }
+            {
+                ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
+                k_radix_scatter<<<grid, kSortThreads, 0, s>>>(ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1],
+                                                             ws.vals[cur ^ 1], cap, ws.geom, shift, pass == 0,
+                                                             n_sort_tiles, ws.hist);
+            }
+            cur ^= 1;
+        }
+        // cur == 0 again after 4 passes
+        const dim3 sgrid(n_seg_tiles, F);
+        {
+            ProfScope ps(pf, O3DR_K_SEGMENT, s);
+            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[cur], cap, ws.geom, n_seg_tiles, ws.seg_cnt);
+        }
+        {
+            ProfScope ps(pf, O3DR_K_OTHER, s);
+            k_scan_rows<<<F, 1024, 0, s>>>(ws.seg_cnt, n_seg_tiles, n_seg_tiles, ws.n_vox, nullptr);
+        }
+        {
+            ProfScope ps(pf, O3DR_K_SEGMENT, s);
+            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[cur], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
+                                              ws.seg_start);
+        }
+        if (v.min_points > 1) {
+            {
+                ProfScope ps(pf, O3DR_K_SEGMENT, s);
+                k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
+                                                  ws.seg_cnt);
+            }
+            {
+                ProfScope ps(pf, O3DR_K_OTHER, s);
+                k_scan_rows<<<F, 1024, 0, s>>>(ws.seg_cnt, n_seg_tiles, n_seg_tiles, ws.n_out, nullptr);
+            }
+            {
+                ProfScope ps(pf, O3DR_K_SEGMENT, s);
+                k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
+                                                  ws.seg_cnt, ws.keep_idx);
+            }
+            n_keep = ws.n_out;
+        }
+    }
+    {
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        k_frame_offsets<<<1, 1, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc);
+    }
+    if (cap > 0) {
+        ProfScope ps(pf, O3DR_K_CENTROID, s);
+        k_centroid<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
+            v.in, v.in_fstride, ws.vals[0], cap, ws.seg_start, (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr,
+            ws.geom, ws.n_out, ws.out_off, v.z_offset, v.passthrough, v.out_base);
+    }
+}
+
+}  // namespace o3dr

@@ -1,0 +1,335 @@
+/*
+ * o3dr_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see o3dr_oracle.h).
+ *
+ * Plain-C restatement of the reference's per-frame reconstruction arithmetic.  Each function cites
+ * the reference lines it follows (paths relative to the reference tree) and, where the arithmetic
+ * lives in a third-party library that is not in the reference tree, the library + version whose
+ * published algorithm is restated:
+ *     OpenCV 3.1.0  (build/CMakeFiles/pose.dir/link.txt)   cv::Mat_<double> product, Mat /= scalar
+ *     PCL 1.8.x     (build/CMakeCache.txt:412)             transformPointCloud, VoxelGrid,
+ *                                                          CentroidPoint, getMinMax3D
+ * Parity unpinned by the reference (it has no tests); pinned here by analytic known answers
+ * (tests/test_oracle_golden.py).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).  The reference was compiled
+ * without -O (build/CMakeFiles/pose.dir/flags.make), so no multiply-add was ever fused; x86-64 SSE2
+ * evaluates float expressions in float and double expressions in double, as this file assumes.
+ */
+#include "o3dr_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * A1: per-pixel reprojection.  pose_functions.cpp:1110-1121 (grid pass) == :1074-1083 (keypoints):
+ *     vec = (x, y, disp, 1);  vec = Q*vec;  vec /= vec(3);  pt = (float)vec(0..2);
+ *     rgb = R<<16 | G<<8 | B from the BGR pixel.
+ * cv::Mat_<double>(4x4)*(4x1) goes through cv::gemm's small-matrix path, which evaluates each row
+ * as a0*b0 + a1*b1 + a2*b2 + a3*b3 left to right in double [OpenCV 3.1 core/src/matmul.cpp].
+ * `Mat /= s` is `convertTo(m, -1, 1./s)`, i.e. every element becomes v*(1./s) + 0
+ * [OpenCV 3.1 core/src/operations / convert.cpp cvtScale_].
+ * ---------------------------------------------------------------------------------------------- */
+static inline void reproject_pixel(const double Q[16], int x, int y, double d, const uint8_t* bgr_px,
+                                   orc_point* pt)
+{
+    const double v0 = (double)x, v1 = (double)y, v2 = d, v3 = 1.0;
+    double t[4];
+    for (int r = 0; r < 4; ++r) {
+        const double* q = Q + 4 * r;
+        t[r] = ((q[0] * v0 + q[1] * v1) + q[2] * v2) + q[3] * v3;
+    }
+    const double alpha = 1. / t[3];
+    const double X = t[0] * alpha + 0.0;
+    const double Y = t[1] * alpha + 0.0;
+    const double Z = t[2] * alpha + 0.0;
+    pt->x = (float)X;
+    pt->y = (float)Y;
+    pt->z = (float)Z;
+    /* Vec3b color = rgb_image.at<Vec3b>(Point(x,y)); color[2]<<16 | color[1]<<8 | color[0] */
+    pt->rgba = ((uint32_t)bgr_px[2] << 16) | ((uint32_t)bgr_px[1] << 8) | (uint32_t)bgr_px[0];
+}
+
+int64_t orc_create_single_img_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
+                                       const uint8_t* bgr, int64_t bgr_pitch,
+                                       int32_t rows, int32_t cols, const double Q[16],
+                                       int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                       double min_disparity, int32_t jump_pixels,
+                                       const float* kp_xy, int32_t n_kp, orc_point* out)
+{
+    int64_t n = 0;
+    /* keypoint pass — pose_functions.cpp:1057-1091 */
+    if (jump_pixels != 1) {
+        for (int32_t i = 0; i < n_kp; ++i) {
+            const int x = (int)kp_xy[2 * i], y = (int)kp_xy[2 * i + 1]; /* :1061 float -> int */
+            if (x >= cols_start_aft_cutout && x < cols - bounding_box && y >= bounding_box &&
+                y < rows - bounding_box) { /* :1062 */
+                const double d = (double)disp[(int64_t)y * disp_pitch + x];
+                if (d > min_disparity) /* :1070 */
+                    reproject_pixel(Q, x, y, d, bgr + (int64_t)y * bgr_pitch + 3 * (int64_t)x, &out[n++]);
+            }
+        }
+    }
+    /* grid pass — pose_functions.cpp:1092-1130 */
+    if (jump_pixels > 0) {
+        for (int y = bounding_box; y < rows - bounding_box; y += jump_pixels) {
+            for (int x = cols_start_aft_cutout; x < cols - bounding_box; x += jump_pixels) {
+                const double d = (double)disp[(int64_t)y * disp_pitch + x]; /* :1104 */
+                if (d > min_disparity)                                       /* :1107 */
+                    reproject_pixel(Q, x, y, d, bgr + (int64_t)y * bgr_pitch + 3 * (int64_t)x, &out[n++]);
+            }
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A2: pcl::transformPointCloud(cloud_in, cloud_out, Matrix4f), dense branch
+ * [PCL 1.8 common/impl/transforms.hpp]:
+ *     out.x = static_cast<float>(t(0,0)*pt(0) + t(0,1)*pt(1) + t(0,2)*pt(2) + t(0,3));  (y, z alike)
+ * all operands float, evaluated left to right; the other fields are copied.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_transform_pt_cloud(const orc_point* in, int64_t n, const float T[16], orc_point* out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float x = in[i].x, y = in[i].y, z = in[i].z;
+        orc_point o;
+        o.x = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+        o.y = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+        o.z = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+        o.rgba = in[i].rgba;
+        out[i] = o;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A4: pcl::VoxelGrid<PointXYZRGB>::applyFilter [PCL 1.8 filters/impl/voxel_grid.hpp], with the
+ * defaults the reference leaves in place: no filter field, downsample_all_data_ = true,
+ * save_leaf_layout_ = false, dense input (createSingleImgPtCloud sets is_dense, :1033).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct voxel_grid_geom {
+    float inv[3];
+    int32_t min_b[3], max_b[3], div_b[3], divb_mul[3];
+    int overflow;
+} voxel_grid_geom;
+
+static void voxel_grid_setup(const orc_point* in, int64_t n, const float leaf[3], voxel_grid_geom* g)
+{
+    /* setLeafSize: inverse_leaf_size_ = Array4f::Ones() / leaf_size_.array()  (fp32 division) */
+    for (int a = 0; a < 3; ++a) g->inv[a] = 1.0f / leaf[a];
+
+    /* getMinMax3D(cloud, indices, min_p, max_p): component-wise fp32 min/max from +-FLT_MAX */
+    float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int64_t i = 0; i < n; ++i) {
+        const float p[3] = {in[i].x, in[i].y, in[i].z};
+        for (int a = 0; a < 3; ++a) {
+            if (p[a] < min_p[a]) min_p[a] = p[a];
+            if (p[a] > max_p[a]) max_p[a] = p[a];
+        }
+    }
+    /* int64_t dx = static_cast<int64_t>((max_p[0]-min_p[0]) * inverse_leaf_size_[0]) + 1; ...
+       if (dx*dy*dz > INT32_MAX) { warn; output = *input_; return; } */
+    int64_t d[3];
+    for (int a = 0; a < 3; ++a) d[a] = (int64_t)((max_p[a] - min_p[a]) * g->inv[a]) + 1;
+    g->overflow = (d[0] * d[1] * d[2]) > (int64_t)INT32_MAX;
+
+    /* min_b_[a] = static_cast<int>(floor(min_p[a] * inverse_leaf_size_[a])); max_b_ alike */
+    for (int a = 0; a < 3; ++a) {
+        g->min_b[a] = (int32_t)floor((double)(min_p[a] * g->inv[a]));
+        g->max_b[a] = (int32_t)floor((double)(max_p[a] * g->inv[a]));
+        g->div_b[a] = g->max_b[a] - g->min_b[a] + 1;
+    }
+    g->divb_mul[0] = 1;
+    g->divb_mul[1] = g->div_b[0];
+    g->divb_mul[2] = (int32_t)((uint32_t)g->div_b[0] * (uint32_t)g->div_b[1]);
+}
+
+static inline uint32_t voxel_key(const voxel_grid_geom* g, float x, float y, float z)
+{
+    /* ijk0 = static_cast<int>(floor(p.x * inverse_leaf_size_[0]) - static_cast<float>(min_b_[0]));
+       The product is fp32; floor() of it and the subtraction are exact for |cell| < 2^24 whether
+       they are carried out in float or in double (GCC 5's unqualified floor -> double). */
+    const int32_t i0 = (int32_t)(floor((double)(x * g->inv[0])) - (double)(float)g->min_b[0]);
+    const int32_t i1 = (int32_t)(floor((double)(y * g->inv[1])) - (double)(float)g->min_b[1]);
+    const int32_t i2 = (int32_t)(floor((double)(z * g->inv[2])) - (double)(float)g->min_b[2]);
+    /* int idx = ijk0*divb_mul_[0] + ijk1*divb_mul_[1] + ijk2*divb_mul_[2]; -> unsigned int */
+    return (uint32_t)i0 * (uint32_t)g->divb_mul[0] + (uint32_t)i1 * (uint32_t)g->divb_mul[1] +
+           (uint32_t)i2 * (uint32_t)g->divb_mul[2];
+}
+
+uint32_t orc_voxel_keys(const orc_point* in, int64_t n, const float leaf[3], uint32_t* keys,
+                        int32_t min_b[3], int32_t div_b[3])
+{
+    voxel_grid_geom g;
+    if (n <= 0) return 0;
+    voxel_grid_setup(in, n, leaf, &g);
+    for (int a = 0; a < 3; ++a) {
+        if (min_b) min_b[a] = g.min_b[a];
+        if (div_b) div_b[a] = g.div_b[a];
+    }
+    if (g.overflow) return ORC_STATUS_VOXEL_OVERFLOW;
+    for (int64_t i = 0; i < n; ++i) keys[i] = voxel_key(&g, in[i].x, in[i].y, in[i].z);
+    return 0;
+}
+
+/* stable LSD radix sort of (key, value) pairs: equal keys keep ascending input index */
+static void stable_sort_pairs(uint32_t* key, uint32_t* val, int64_t n)
+{
+    uint32_t* k2 = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+    uint32_t* v2 = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+    uint32_t *ka = key, *va = val, *kb = k2, *vb = v2;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = 8 * pass;
+        int64_t cnt[257];
+        memset(cnt, 0, sizeof cnt);
+        for (int64_t i = 0; i < n; ++i) cnt[((ka[i] >> sh) & 255u) + 1]++;
+        for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t p = cnt[(ka[i] >> sh) & 255u]++;
+            kb[p] = ka[i];
+            vb[p] = va[i];
+        }
+        uint32_t* t;
+        t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+    }
+    /* 4 passes: result is back in key/val */
+    free(k2);
+    free(v2);
+}
+
+int64_t orc_voxel_grid(const orc_point* in, int64_t n, const float leaf[3], uint32_t min_points,
+                       int32_t order, orc_point* out, uint32_t* status)
+{
+    if (status) *status = 0;
+    if (n <= 0) return 0;
+    voxel_grid_geom g;
+    voxel_grid_setup(in, n, leaf, &g);
+    if (g.overflow) { /* "Leaf size is too small ... Integer indices would overflow": output = input */
+        if (status) *status = ORC_STATUS_VOXEL_OVERFLOW;
+        if (out != in) memmove(out, in, (size_t)n * sizeof(orc_point));
+        return n;
+    }
+    /* first pass: (idx, cloud_point_index) for every point */
+    uint32_t* key = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+    uint32_t* pid = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+    for (int64_t i = 0; i < n; ++i) {
+        key[i] = voxel_key(&g, in[i].x, in[i].y, in[i].z);
+        pid[i] = (uint32_t)i;
+    }
+    /* second pass: std::sort(index_vector.begin(), index_vector.end(), std::less<...>()) on idx.
+       std::sort is not stable, so the order of the points inside one voxel is whatever libstdc++'s
+       introsort leaves; ORC_ORDER_STDSORT reproduces that, ORC_ORDER_STABLE is the canonical
+       ascending-input-index order. */
+    if (order == ORC_ORDER_STDSORT)
+        orc_stdsort_pairs(key, pid, n);
+    else
+        stable_sort_pairs(key, pid, n);
+
+    /* third + fourth pass: runs of equal idx with >= min_points_per_voxel_ points become one output
+       point each, via CentroidPoint<PointXYZRGB> [PCL 1.8 common/impl/accumulators.hpp]:
+         AccumulatorXYZ : Vector3f xyz += p.xyz;            get: xyz / n   (fp32 sums, fp32 divide)
+         AccumulatorRGBA: float r,g,b,a += channel;          get: uint32_t(c / n) per channel */
+    int64_t m = 0;
+    orc_point* dst = out;
+    orc_point* tmp = NULL;
+    if (out == in) { /* allow in-place use */
+        tmp = (orc_point*)malloc((size_t)n * sizeof(orc_point));
+        dst = tmp;
+    }
+    int64_t index = 0;
+    while (index < n) {
+        int64_t i = index + 1;
+        while (i < n && key[i] == key[index]) ++i;
+        if ((uint64_t)(i - index) >= (uint64_t)min_points) {
+            float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
+            for (int64_t li = index; li < i; ++li) {
+                const orc_point* p = &in[pid[li]];
+                sx += p->x;
+                sy += p->y;
+                sz += p->z;
+                sr += (float)((p->rgba >> 16) & 255u);
+                sg += (float)((p->rgba >> 8) & 255u);
+                sb += (float)(p->rgba & 255u);
+                sa += (float)((p->rgba >> 24) & 255u);
+            }
+            const float nf = (float)(uint64_t)(i - index);
+            orc_point o;
+            o.x = sx / nf;
+            o.y = sy / nf;
+            o.z = sz / nf;
+            o.rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) |
+                     ((uint32_t)(sg / nf) << 8) | (uint32_t)(sb / nf);
+            dst[m++] = o;
+        }
+        index = i;
+    }
+    if (tmp) {
+        memcpy(out, tmp, (size_t)m * sizeof(orc_point));
+        free(tmp);
+    }
+    free(key);
+    free(pid);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A3a / A5: Pose::downsamplePtCloud, pose_functions.cpp:1654-1709.
+ *   copy loop with `z += 500` when combined                          :1660-1669
+ *   [StatisticalOutlierRemoval when !combined && jump_pixels > 0     :1673-1686 — NOT applied here]
+ *   VoxelGrid leaf (vs,vs,1000) + min_points_per_voxel, or (vs/5)^3   :1689-1700
+ *   `z -= 500` when combined                                          :1702-1704
+ * voxel_size is a double (pose.h:118); setLeafSize takes floats, so vs and vs/5 are narrowed.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t orc_downsample_pt_cloud(const orc_point* in, int64_t n, double voxel_size, int32_t combined,
+                                uint32_t min_points_per_voxel, int32_t order, orc_point* out,
+                                uint32_t* status)
+{
+    if (status) *status = 0;
+    if (n <= 0) return 0;
+    orc_point* work = (orc_point*)malloc((size_t)n * sizeof(orc_point));
+    memcpy(work, in, (size_t)n * sizeof(orc_point));
+    float leaf[3];
+    uint32_t min_pts;
+    if (combined) {
+        for (int64_t i = 0; i < n; ++i) work[i].z += 500; /* fp32: float += int -> float */
+        leaf[0] = (float)voxel_size;
+        leaf[1] = (float)voxel_size;
+        leaf[2] = 1000.0f;
+        min_pts = min_points_per_voxel;
+    } else {
+        leaf[0] = leaf[1] = leaf[2] = (float)(voxel_size / 5);
+        min_pts = 0; /* PCL default min_points_per_voxel_ */
+    }
+    const int64_t m = orc_voxel_grid(work, n, leaf, min_pts, order, out, status);
+    if (combined)
+        for (int64_t i = 0; i < m; ++i) out[i].z -= 500;
+    free(work);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A6: Pose::createAndTransformPtCloud, pose.cpp:596-636: A1 -> A2 -> (A3a unless dont_downsample).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t orc_create_and_transform_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
+                                          const uint8_t* bgr, int64_t bgr_pitch,
+                                          int32_t rows, int32_t cols, const double Q[16],
+                                          int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                          double min_disparity, int32_t jump_pixels,
+                                          const float* kp_xy, int32_t n_kp, const float T[16],
+                                          double voxel_size, int32_t dont_downsample, int32_t order,
+                                          orc_point* scratch, orc_point* out, uint32_t* status)
+{
+    if (status) *status = 0;
+    const int64_t n = orc_create_single_img_pt_cloud(disp, disp_pitch, bgr, bgr_pitch, rows, cols, Q,
+                                                     bounding_box, cols_start_aft_cutout,
+                                                     min_disparity, jump_pixels, kp_xy, n_kp, scratch);
+    orc_point* tr = scratch + n;
+    orc_transform_pt_cloud(scratch, n, T, tr);
+    if (dont_downsample) {
+        memcpy(out, tr, (size_t)n * sizeof(orc_point));
+        return n;
+    }
+    return orc_downsample_pt_cloud(tr, n, voxel_size, 0, 0, order, out, status);
+}

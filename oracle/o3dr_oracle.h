@@ -1,0 +1,76 @@
+/*
+ * o3dr_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's per-frame reconstruction path, used only as the parity
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under
+ * online_3d_reconstruction_amd/ may include, link or call this.
+ *
+ * PARITY PINNING: the reference ships no tests, golden vectors or fixtures for this path, and it
+ * cannot be built here (OpenCV 3.1+CUDA, PCL 1.8, Boost, VTK, Eigen, FLANN are absent; SURVEY.md
+ * section 8c) — so this oracle is pinned by analytic known-answer vectors derived from the bundled
+ * calibration (cam13calib.yml) and by invariants of the bundled output cloud (build/cloud.ply),
+ * not by outputs of the reference itself: "parity unpinned" in the sense of the task statement.
+ */
+#ifndef O3DR_ORACLE_H
+#define O3DR_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_point {
+    float    x, y, z;
+    uint32_t rgba; /* a<<24 | r<<16 | g<<8 | b */
+} orc_point;
+
+/* order in which the points of one voxel are summed */
+#define ORC_ORDER_STABLE  0 /* ascending input index (canonical; what libo3dr implements) */
+#define ORC_ORDER_STDSORT 1 /* libstdc++ std::sort on (idx, point index) comparing idx only — the
+                               call PCL makes; implemented in o3dr_oracle_stdsort.cpp */
+
+#define ORC_STATUS_VOXEL_OVERFLOW 1u
+
+/* A1 — Pose::createSingleImgPtCloud, pose_functions.cpp:1030-1134.  Returns the point count.
+ * `out` must hold n_kp + Ny*Nx points. */
+int64_t orc_create_single_img_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
+                                       const uint8_t* bgr, int64_t bgr_pitch,
+                                       int32_t rows, int32_t cols, const double Q[16],
+                                       int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                       double min_disparity, int32_t jump_pixels,
+                                       const float* kp_xy, int32_t n_kp, orc_point* out);
+
+/* A2 — Pose::transformPtCloud, pose_functions.cpp:1358-1362 -> pcl::transformPointCloud (dense). */
+void orc_transform_pt_cloud(const orc_point* in, int64_t n, const float T[16], orc_point* out);
+
+/* A4 — pcl::VoxelGrid<PointXYZRGB>::applyFilter (PCL 1.8).  Returns the output count. */
+int64_t orc_voxel_grid(const orc_point* in, int64_t n, const float leaf[3], uint32_t min_points,
+                       int32_t order, orc_point* out, uint32_t* status);
+
+/* A3a/A5 — Pose::downsamplePtCloud, pose_functions.cpp:1654-1709 (statistical outlier removal,
+ * :1673-1686, is not applied: see SURVEY.md section 8a row A3b). */
+int64_t orc_downsample_pt_cloud(const orc_point* in, int64_t n, double voxel_size, int32_t combined,
+                                uint32_t min_points_per_voxel, int32_t order, orc_point* out,
+                                uint32_t* status);
+
+/* A6 — Pose::createAndTransformPtCloud, pose.cpp:596-636.  `scratch` holds 2*(n_kp+Ny*Nx) points. */
+int64_t orc_create_and_transform_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
+                                          const uint8_t* bgr, int64_t bgr_pitch,
+                                          int32_t rows, int32_t cols, const double Q[16],
+                                          int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                          double min_disparity, int32_t jump_pixels,
+                                          const float* kp_xy, int32_t n_kp, const float T[16],
+                                          double voxel_size, int32_t dont_downsample, int32_t order,
+                                          orc_point* scratch, orc_point* out, uint32_t* status);
+
+/* voxel keys only (occupancy checks): writes the uint32 linear index PCL computes for each point,
+ * returns 0, or ORC_STATUS_VOXEL_OVERFLOW when PCL would bail out (keys then undefined). */
+uint32_t orc_voxel_keys(const orc_point* in, int64_t n, const float leaf[3], uint32_t* keys,
+                        int32_t min_b[3], int32_t div_b[3]);
+
+/* provided by o3dr_oracle_stdsort.cpp: sorts (idx, point index) pairs exactly as PCL does */
+void orc_stdsort_pairs(uint32_t* idx, uint32_t* point_index, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

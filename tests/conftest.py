@@ -1,0 +1,77 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure: oracle/)."""
+    from oracle import orc as _orc
+    _orc.build()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def Q():
+    return np.load(os.path.join(GOLDEN, "cam13calib_Q.npy"))
+
+
+def load_frame(name):
+    z = np.load(os.path.join(GOLDEN, f"frame_{name}.npz"))
+    return z["disp"], z["bgr"]
+
+
+@pytest.fixture(scope="session")
+def frame_B():
+    return load_frame("B")
+
+
+@pytest.fixture(scope="session")
+def frame_1248():
+    return load_frame("1248")
+
+
+@pytest.fixture(scope="session")
+def frame_1249():
+    return load_frame("1249")
+
+
+@pytest.fixture(scope="session")
+def ctx(Q):
+    """A libo3dr context on cuda:0 (gpu tests only)."""
+    import online_3d_reconstruction_amd as o3dr
+    c = o3dr.Context(0, Q=Q)
+    yield c
+    c.close()
+
+
+def random_cloud(n, seed, extent=(8.0, 6.0, 3.0), origin=(3.0, -4.0, -2.0)):
+    """n points uniformly inside a box, random colours (alpha 0 like the reference's clouds)."""
+    from oracle.orc import POINT
+    rng = np.random.default_rng(seed)
+    p = np.empty(n, POINT)
+    for k, ax in enumerate("xyz"):
+        p[ax] = (origin[k] + extent[k] * rng.random(n)).astype(np.float32)
+    p["rgba"] = rng.integers(0, 1 << 24, n, dtype=np.uint32)
+    return p
+
+
+def assert_points_equal(a, b, what=""):
+    """bit-exact comparison of two POINT arrays with a useful message."""
+    assert len(a) == len(b), f"{what}: count {len(a)} != {len(b)}"
+    av = np.ascontiguousarray(a).view(np.uint32).reshape(-1, 4)
+    bv = np.ascontiguousarray(b).view(np.uint32).reshape(-1, 4)
+    bad = np.nonzero((av != bv).any(axis=1))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {len(a)} points differ, first at {bad[0]}: {a[bad[0]]} vs {b[bad[0]]}"

@@ -1,0 +1,63 @@
+"""Regenerates the fixtures in this directory from the DATA files bundled with the reference
+(run once in the build container, where /root/reference is mounted; the GPU box only sees the
+committed outputs).  Only data travels: decoded pixels of bundled PNGs, the calibration numbers,
+and the vertices of the bundled output cloud.  No reference source is read or copied.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import re
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference/build"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def read_Q(path):
+    txt = open(path).read()
+    m = re.search(r"Q: !!opencv-matrix.*?data: \[(.*?)\]", txt, re.S)
+    return np.array([float(v) for v in m.group(1).replace("\n", " ").split(",")], np.float64).reshape(4, 4)
+
+
+def load_pair(name):
+    disp = np.array(Image.open(f"{REF}/disparities/{name}.png").convert("L"))  # IMREAD_GRAYSCALE, :548
+    rgb = np.array(Image.open(f"{REF}/images/{name}.png").convert("RGB"))
+    return disp, np.ascontiguousarray(rgb[:, :, ::-1])  # cv::imread gives B,G,R (:526)
+
+
+def read_ply_vertices(path):
+    raw = open(path, "rb").read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    header = raw[:end].decode()
+    n = int(re.search(r"element vertex (\d+)", header).group(1))
+    dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    v = np.frombuffer(raw, dt, n, end)
+    return header, v, raw[end + n * dt.itemsize:]
+
+
+def main():
+    Q = read_Q(f"{REF}/data_files/cam13calib.yml")
+    np.save(f"{OUT}/cam13calib_Q.npy", Q)
+
+    # synthetic pair shipped with the reference (two disparities, two colours)
+    d, c = load_pair("B")
+    np.savez_compressed(f"{OUT}/frame_B.npz", disp=d, bgr=c)
+
+    # two real frames inside config 1's range that have both image and disparity
+    for name in ("1248", "1249"):
+        d, c = load_pair(name)
+        np.savez_compressed(f"{OUT}/frame_{name}.npz", disp=d, bgr=c)
+
+    # bundled output cloud: layout fixture + "one point per 0.05 m XY cell" invariant
+    header, v, tail = read_ply_vertices(f"{REF}/cloud.ply")
+    np.savez_compressed(f"{OUT}/cloud_ply.npz", header=np.frombuffer(header.encode(), np.uint8),
+                        vertices=v, tail=np.frombuffer(tail, np.uint8))
+    print("Q =", Q.ravel())
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(f"{OUT}/{f}"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: libo3dr.so loads and exports exactly what include/o3dr.h
+declares; without a GPU the product path fails loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "o3dr.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(o3dr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from online_3d_reconstruction_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 25
+    L = C.CDLL(_lib.lib_path())
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/o3dr.h but not exported by libo3dr.so"
+    bound = sorted(n for n, _, _ in _lib.SYMBOLS)
+    assert bound == names, set(bound) ^ set(names)
+
+
+def test_version_and_defaults():
+    from online_3d_reconstruction_amd import _lib
+    L = _lib.load_library()
+    assert L.o3dr_version() == 100
+    p = _lib.ParamsStruct()
+    L.o3dr_default_params(C.byref(p))
+    # pose.h:93-126
+    assert (p.min_disparity, p.voxel_size, p.bounding_box, p.cutout_ratio, p.jump_pixels, p.min_points_per_voxel) == \
+        (64.0, 0.1, 20, 8, 10, 1)
+
+
+def test_point_layout_is_16_bytes():
+    from online_3d_reconstruction_amd import POINT
+    assert POINT.itemsize == 16 and POINT.fields["rgba"][1] == 12
+
+
+def test_product_path_does_not_touch_the_oracle():
+    """Nothing under the package may import, include, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "online_3d_reconstruction_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle|#\s*include\s*[\"<][^\n]*oracle|liborc|oracle/_build|orc_[a-z_]+\(", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".c")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not pat.search(txt), f"{os.path.join(dirpath, f)} references the oracle"
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import online_3d_reconstruction_amd as o3dr
+    with pytest.raises(o3dr.O3drError) as e:
+        o3dr.Context(0)
+    assert e.value.code == -2  # O3DR_ERR_NO_DEVICE
+
+
+def test_null_context_is_rejected():
+    from online_3d_reconstruction_amd import _lib
+    L = _lib.load_library()
+    n = C.c_int64(7)
+    st = C.c_uint32(7)
+    leaf = np.array([1, 1, 1], np.float32)
+    rc = L.o3dr_voxel_grid(None, None, 0, leaf.ctypes.data, 0, 0.0, None, 0, C.byref(n), C.byref(st), 0)
+    assert rc == -1 and n.value == 0  # invalid arg, output left empty
+    assert b"ctx" in L.o3dr_last_error()

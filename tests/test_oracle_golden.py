@@ -1,0 +1,243 @@
+"""CPU tests: the oracle against every known answer the reference's bundled data supports
+(SURVEY.md section 8c).  The reference has no tests of its own; these vectors are analytic."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, random_cloud
+
+# fp64 -> fp32 known answers from Q (cam13calib.yml:91-97): (x, y, d) -> (X, Y, Z)
+ANALYTIC = [
+    ((160, 20, 128), (-1.688523769, -2.289067745, 19.608304977)),
+    ((200, 100, 142), (-1.354909658, -1.729104996, 17.675092697)),
+    ((1259, 699, 128), (3.405915022, 0.858451903, 19.608304977)),
+    ((160, 20, 65), (-3.325093031, -4.507702351, 38.613277435)),
+    ((160, 20, 255), (-0.847572744, -1.149022222, 9.842600822)),
+]
+
+
+@pytest.mark.parametrize("pix,xyz", ANALYTIC)
+def test_analytic_reprojection(orc, Q, pix, xyz):
+    x, y, d = pix
+    disp = np.zeros((720, 1280), np.uint8)
+    bgr = np.zeros((720, 1280, 3), np.uint8)
+    disp[y, x] = d
+    bgr[y, x] = (10, 20, 30)  # B, G, R
+    p = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)
+    assert len(p) == 1
+    exp = np.array(xyz, np.float64).astype(np.float32)
+    got = np.array([p["x"][0], p["y"][0], p["z"][0]], np.float32)
+    assert np.array_equal(got, exp), (got, exp)
+    # independent closed form: X=(x-cx)/(Q32 d), Y=(y-cy)/(Q32 d), Z=f/(Q32 d)
+    W = Q[3, 2] * d
+    closed = np.array([(x + Q[0, 3]) / W, (y + Q[1, 3]) / W, Q[2, 3] / W])
+    assert np.abs(got - closed).max() < 2e-6
+    assert p["rgba"][0] == (30 << 16) | (20 << 8) | 10  # R<<16|G<<8|B, alpha 0
+
+
+def test_min_disparity_is_strict(orc, Q):
+    disp = np.full((720, 1280), 64, np.uint8)
+    bgr = np.zeros((720, 1280, 3), np.uint8)
+    assert len(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)) == 0
+    disp[:] = 65
+    assert len(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)) == 680 * 1100
+
+
+def test_roi_counts_match_reference_log(orc, Q, frame_B):
+    """ROI = (720-40) x (1280-160-20) = 748000 candidates at jump 1 (build/output/log.txt reports
+    747512..747793 points for dense frames, i.e. this ROI minus d<=64 pixels); 46 x 74 at jump 15."""
+    disp, bgr = frame_B
+    p = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)
+    assert len(p) == 748000
+    assert orc.grid_shape(720, 1280, 20, 8, 15)[:2] == (46, 74)
+    assert len(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=15)) == 46 * 74
+
+
+def test_synthetic_pair_B(orc, Q, frame_B):
+    """build/disparities/B.png + build/images/B.png: two disparities (128 background, 142 inside the
+    rectangle rows 99..199 x cols 199..399), two colours (green background, red rectangle)."""
+    disp, bgr = frame_B
+    assert set(np.unique(disp)) == {128, 142}
+    p = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)
+    z = np.unique(p["z"])
+    assert np.array_equal(z, np.array([17.675092697, 19.608304977], np.float64).astype(np.float32))
+    near = p["z"] == z[0]
+    assert near.sum() == 101 * 201  # whole rectangle lies inside the ROI
+    assert set(np.unique(p["rgba"][near])) == {0xFF0000}
+    assert set(np.unique(p["rgba"][~near])) == {0x00FF00}
+    # order is row-major: first point is pixel (x=160, y=20)
+    assert np.float32(p["x"][0]) == np.float32((160 + Q[0, 3]) * (1.0 / (Q[3, 2] * 128)))
+
+
+def test_keypoint_pass_precedes_grid_and_respects_roi(orc, Q, frame_B):
+    disp, bgr = frame_B
+    kp = np.array([[300.7, 150.2], [10.0, 10.0], [1259.9, 699.9], [1260.0, 300.0], [160.0, 19.9]], np.float32)
+    p = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=15, kp_xy=kp)
+    assert len(p) == 2 + 46 * 74  # (300,150) and (1259,699) pass the ROI test of :1062
+    W = Q[3, 2] * 142
+    assert np.float32(p["x"][0]) == np.float32((300 + Q[0, 3]) * (1.0 / W))
+    # jump_pixels == 1 skips the keypoint pass (:1057), jump_pixels == 0 keeps only keypoints
+    assert len(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1, kp_xy=kp)) == 748000
+    assert len(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=0, kp_xy=kp)) == 2
+
+
+def test_transform_is_unfused_fp32(orc):
+    rng = np.random.default_rng(0)
+    pts = random_cloud(1000, 1)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :] = rng.standard_normal((3, 4)).astype(np.float32)
+    out = orc.transform_pt_cloud(pts, T)
+    x, y, z = pts["x"], pts["y"], pts["z"]
+    for r, ax in enumerate("xyz"):
+        exp = ((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3]  # numpy float32: no FMA
+        assert np.array_equal(out[ax], exp)
+    assert np.array_equal(out["rgba"], pts["rgba"])
+    ident = orc.transform_pt_cloud(pts, np.eye(4, dtype=np.float32))
+    assert np.array_equal(ident.view(np.uint32), pts.view(np.uint32))
+
+
+def test_frame_1248_pose_world_point(orc, Q):
+    """under the pose generateTmat gives for frame 1248 (pose.txt row 638), a pixel
+    (x=700, y=360) with disparity 108 lands at world (6.99899, -13.26695, -1.57852)."""
+    from online_3d_reconstruction_amd import synth
+    disp = np.zeros((720, 1280), np.uint8)
+    bgr = np.zeros((720, 1280, 3), np.uint8)
+    disp[360, 700] = 108
+    T = synth.generate_tmat((7.70684, -12.120081, 21.99), (0.003113, -0.000385, 0.409214, -0.912433))
+    cam = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)
+    assert len(cam) == 1
+    w = orc.transform_pt_cloud(cam, T)
+    got = np.array([w["x"][0], w["y"][0], w["z"][0]])
+    assert np.abs(got - np.array([6.99899, -13.26695, -1.57852])).max() < 2e-5
+
+
+def _cells(p, vs):
+    return np.stack([np.floor(p["x"] / vs), np.floor(p["y"] / vs)], 1).astype(np.int64)
+
+
+def test_bundled_cloud_ply_is_one_point_per_xy_cell(orc):
+    """build/cloud.ply (55940 vertices, 15 B each + one camera element) is the output of the combined
+    merge at voxel_size 0.05: exactly one point per 0.05 m XY cell (pose_functions.cpp:1666,1694)."""
+    z = np.load(os.path.join(GOLDEN, "cloud_ply.npz"))
+    v = z["vertices"]
+    assert len(v) == 55940 and v.dtype.itemsize == 15
+    assert b"element camera 1" in z["header"].tobytes()
+    cells = _cells(v, np.float32(0.05))
+    assert len(np.unique(cells, axis=0)) == 55940
+    # ... and the oracle's combined merge leaves it one-per-cell (fixed point of occupancy)
+    p = np.zeros(len(v), orc.POINT)
+    p["x"], p["y"], p["z"] = v["x"], v["y"], v["z"]
+    p["rgba"] = (v["r"].astype(np.uint32) << 16) | (v["g"].astype(np.uint32) << 8) | v["b"]
+    out, st = orc.downsample_pt_cloud(p, 0.05, True, 1)
+    assert st == 0 and len(out) == 55940
+
+
+def test_voxel_grid_against_bruteforce(orc):
+    """Occupancy, order, counts and centroids against an independent numpy grouping."""
+    pts = random_cloud(20000, 7, extent=(2.0, 1.5, 0.5))
+    leaf = np.array([0.05, 0.07, 0.11], np.float32)
+    out, st = orc.voxel_grid(pts, leaf, 0)
+    assert st == 0
+    inv = np.float32(1.0) / leaf
+    ijk = np.stack([np.floor(pts[a] * inv[k]) for k, a in enumerate("xyz")], 1).astype(np.int64)
+    ijk -= ijk.min(0)
+    div = ijk.max(0) + 1
+    lin = ijk[:, 0] + div[0] * (ijk[:, 1] + div[1] * ijk[:, 2])
+    uniq, first, cnt = np.unique(lin, return_index=True, return_counts=True)
+    assert len(out) == len(uniq)  # one point per occupied voxel, ascending linear index
+    order = np.argsort(lin, kind="stable")
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    for v in (0, len(uniq) // 2, len(uniq) - 1):
+        sel = order[starts[v]: starts[v] + cnt[v]]
+        s = np.float32(0)
+        for i in sel:
+            s = np.float32(s + pts["x"][i])
+        assert out["x"][v] == np.float32(s / np.float32(cnt[v]))
+        r = ((pts["rgba"][sel] >> 16) & 255).astype(np.float32).sum(dtype=np.float32)
+        assert (out["rgba"][v] >> 16) & 255 == int(np.float32(r / np.float32(cnt[v])))
+    # every output point lies inside its voxel
+    oi = np.stack([np.floor(out[a] * inv[k]) for k, a in enumerate("xyz")], 1).astype(np.int64)
+    oi -= np.stack([np.floor(pts[a] * inv[k]) for k, a in enumerate("xyz")], 1).astype(np.int64).min(0)
+    assert np.array_equal(oi[:, 0] + div[0] * (oi[:, 1] + div[1] * oi[:, 2]), uniq)
+
+
+def test_min_points_per_voxel(orc):
+    pts = random_cloud(5000, 3, extent=(1.0, 1.0, 0.2))
+    leaf = np.array([0.1, 0.1, 1000.0], np.float32)
+    all_, _ = orc.voxel_grid(pts, leaf, 0)
+    keys, _, _, _ = orc.voxel_keys(pts, leaf)
+    _, cnt = np.unique(keys, return_counts=True)
+    for m in (1, 2, 40, 60, 10**6):
+        out, _ = orc.voxel_grid(pts, leaf, m)
+        assert len(out) == (cnt >= m).sum()
+    assert len(all_) == len(cnt)
+
+
+def test_overflow_fallback_returns_input(orc):
+    """dx*dy*dz > INT32_MAX -> PCL warns and returns the input cloud unchanged."""
+    pts = random_cloud(1000, 5, extent=(30.0, 30.0, 30.0))
+    out, st = orc.voxel_grid(pts, [0.004, 0.004, 0.004], 0)
+    assert st == orc.STATUS_VOXEL_OVERFLOW
+    assert np.array_equal(out.view(np.uint32), pts.view(np.uint32))
+    # in the combined mode the caller's z += 500 / z -= 500 still wraps the unchanged cloud
+    big = random_cloud(1000, 6, extent=(3000.0, 3000.0, 1.0))
+    out, st = orc.downsample_pt_cloud(big, 0.05, True, 1)
+    assert st == orc.STATUS_VOXEL_OVERFLOW
+    assert np.array_equal(out["z"], (big["z"] + np.float32(500)) - np.float32(500))
+
+
+def test_stdsort_order_vs_stable_order(orc):
+    """PCL's std::sort leaves an unspecified order inside a voxel; the canonical order is ascending
+    input index.  Same occupancy, same colours (integer sums are exact), centroids within fp32
+    summation noise — quantified here because it bounds what 'matches the reference' can mean."""
+    pts = random_cloud(200000, 11, extent=(6.0, 4.0, 1.0))
+    a, _ = orc.downsample_pt_cloud(pts, 0.05, False, 1, orc.ORDER_STABLE)
+    b, _ = orc.downsample_pt_cloud(pts, 0.05, False, 1, orc.ORDER_STDSORT)
+    assert len(a) == len(b)
+    assert np.array_equal(a["rgba"], b["rgba"])
+    for ax in "xyz":
+        assert np.abs(a[ax].astype(np.float64) - b[ax]).max() <= 1e-5
+    # combined mode: z is summed at ~+478 with ~30 points per cell -> noise of a few 1e-5 m
+    ca, _ = orc.downsample_pt_cloud(pts, 0.05, True, 1, orc.ORDER_STABLE)
+    cb, _ = orc.downsample_pt_cloud(pts, 0.05, True, 1, orc.ORDER_STDSORT)
+    assert len(ca) == len(cb) and np.array_equal(ca["rgba"], cb["rgba"])
+    assert np.abs(ca["z"].astype(np.float64) - cb["z"]).max() <= 2e-4
+    assert np.abs(ca["x"].astype(np.float64) - cb["x"]).max() <= 1e-5
+
+
+def test_occupancy_is_permutation_invariant(orc):
+    pts = random_cloud(30000, 13)
+    perm = np.random.default_rng(1).permutation(len(pts))
+    a, _ = orc.downsample_pt_cloud(pts, 0.1, False, 1)
+    b, _ = orc.downsample_pt_cloud(pts[perm], 0.1, False, 1)
+    assert len(a) == len(b) and np.array_equal(a["rgba"], b["rgba"])
+    assert np.abs(a["x"] - b["x"]).max() < 1e-5
+
+
+def test_combined_merge_idempotent_on_own_output(orc):
+    pts = random_cloud(50000, 17, extent=(5.0, 5.0, 2.0))
+    a, _ = orc.downsample_pt_cloud(pts, 0.05, True, 1)
+    b, _ = orc.downsample_pt_cloud(a, 0.05, True, 1)
+    assert len(a) == len(b)
+    assert np.abs(a["x"] - b["x"]).max() == 0 and np.abs(a["z"] - b["z"]).max() <= 6.2e-5  # z re-quantised at +500
+
+
+def test_a6_is_composition(orc, Q, frame_1248):
+    from online_3d_reconstruction_amd import synth
+    disp, bgr = frame_1248
+    T = synth.generate_tmat((7.70684, -12.120081, 21.99), (0.003113, -0.000385, 0.409214, -0.912433))
+    out, st = orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=15)
+    cam = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=15)
+    ref, _ = orc.downsample_pt_cloud(orc.transform_pt_cloud(cam, T), 0.05, False)
+    assert st == 0 and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    raw, _ = orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=15, dont_downsample=True)
+    assert len(raw) == len(cam)
+
+
+def test_empty_inputs(orc, Q):
+    disp = np.zeros((720, 1280), np.uint8)
+    bgr = np.zeros((720, 1280, 3), np.uint8)
+    assert len(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)) == 0
+    out, st = orc.voxel_grid(np.zeros(0, orc.POINT), [0.1, 0.1, 0.1])
+    assert len(out) == 0 and st == 0
