@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark of the reconstruction hot path on MI355X (contract: see the task statement).
+
+One "step" = one pass of the whole hot path over this rank's shard of synthetic frames, inputs
+already resident in HBM:  cloud_big reset -> A6 for every frame (fused reproject + SE(3), per-frame
+voxel grid), appended in frame order -> [N>1: exchange of the per-frame voxel clouds over RCCL] ->
+combined 2.5-D merge (pose.cpp:530).  Workload = BASELINE.json configs[1]: synthetic 1280x720 dense
+(jump_pixels 1), 200 frames per GPU, voxel_size 0.05.
+
+    python bench.py                       # N=1, defaults finish in a few minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _gen(args):
+    from online_3d_reconstruction_amd import synth
+    i, rows, cols, invalid = args
+    return synth.make_frame(i, rows, cols, invalid_frac=invalid)
+
+
+def generate_frames(start, count, rows, cols, invalid, workers):
+    """host-side synthetic frames (before the GPU is touched: the pool forks)"""
+    disp = np.empty((count, rows, cols), np.uint8)
+    bgr = np.empty((count, rows, cols, 3), np.uint8)
+    jobs = [(start + i, rows, cols, invalid) for i in range(count)]
+    if workers > 1:
+        with ProcessPoolExecutor(workers) as ex:
+            for i, (d, c) in enumerate(ex.map(_gen, jobs, chunksize=4)):
+                disp[i], bgr[i] = d, c
+    else:
+        for i, j in enumerate(jobs):
+            disp[i], bgr[i] = _gen(j)
+    return disp, bgr
+
+
+def cpu_baseline(disp, bgr, poses, Q, voxel_size, jump, threads, n_frames):
+    """The CPU oracle (a port of the reference arithmetic, oracle/) timed on this host: A6 for
+    n_frames frames with the reference's own fan-out of `threads` frame-parallel workers
+    (pose.cpp:392-413), then the combined merge.  Statistical outlier removal off, as on the GPU."""
+    from oracle import orc
+    orc.lib()
+
+    def one(i):
+        return orc.create_and_transform_pt_cloud(disp[i], bgr[i], Q, poses[i], voxel_size, jump_pixels=jump)[0]
+
+    t0 = time.perf_counter()
+    if threads > 1:
+        with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C oracle
+            clouds = list(ex.map(one, range(n_frames)))
+    else:
+        clouds = [one(i) for i in range(n_frames)]
+    big = np.concatenate(clouds)
+    orc.downsample_pt_cloud(big, voxel_size, True, 1)
+    dt = time.perf_counter() - t0
+    return n_frames / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=200, help="frames per GPU (weak scaling)")
+    ap.add_argument("--rows", type=int, default=720)
+    ap.add_argument("--cols", type=int, default=1280)
+    ap.add_argument("--jump-pixels", type=int, default=1)
+    ap.add_argument("--voxel-size", type=float, default=0.05)
+    ap.add_argument("--min-points", type=int, default=1)
+    ap.add_argument("--invalid-frac", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=56)
+    ap.add_argument("--cpu-threads", type=int, default=7)
+    ap.add_argument("--gen-workers", type=int, default=min(16, os.cpu_count() or 1))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    # ---- inputs (host) -----------------------------------------------------------------------------
+    from online_3d_reconstruction_amd import synth
+    F = args.frames
+    first = rank * F  # contiguous block of frames per rank
+    disp_h, bgr_h = generate_frames(first, F, args.rows, args.cols, args.invalid_frac, args.gen_workers)
+    poses_h = synth.make_poses(first, F)
+    Q = synth.camera_Q(args.rows, args.cols)
+
+    import torch
+    import torch.distributed as dist
+
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import _lib as L
+    from online_3d_reconstruction_amd import dist as o3dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    stream = torch.cuda.current_stream()
+
+    ctx = o3dr.Context(local_rank, Q=Q, params=o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size,
+                                                          min_points_per_voxel=args.min_points), stream=stream)
+    disp = torch.from_numpy(disp_h).to(dev)
+    bgr = torch.from_numpy(bgr_h).to(dev)
+    poses = torch.from_numpy(poses_h).to(dev)
+    n_cand = ctx.max_points(args.rows, args.cols)
+    ctx.cloudBigReserve(F * n_cand if world == 1 else F * n_cand)
+
+    # valid pixels per frame (for the algorithmic byte counts), from the host copy
+    bb, cs = 20, args.cols // 8
+    roi = disp_h[:, bb:args.rows - bb:max(args.jump_pixels, 1), cs:args.cols - bb:max(args.jump_pixels, 1)]
+    n_valid_total = int((roi > 64).sum())
+
+    state = {}
+
+    def step():
+        ctx.cloudBigReset()
+        ctx.accumulateFrames(disp, bgr, poses)
+        if world > 1:
+            m1 = o3dist.exchange_cloud_big(ctx, dev)
+        else:
+            m1, _ = ctx.cloudBigSize()
+        out = ctx.finalize(device=dev)
+        state["m1_total"] = m1
+        state["m2"] = int(out.shape[0])
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+
+    # one untimed, fully bracketed step: which kernel dominates?
+    barrier()
+    ctx.profileReset()
+    ctx.profileEnable(-1, True)
+    step()
+    per_kernel = {L.KERNEL_NAMES[k]: ctx.profileRead(k) for k in range(len(L.KERNEL_NAMES))}
+    ctx.profileEnable(-1, False)
+    dom = max(range(len(L.KERNEL_NAMES) - 1), key=lambda k: per_kernel[L.KERNEL_NAMES[k]][0])
+
+    # ---- timed region: exactly K steps, only the dominant kernel bracketed by HIP events -----------
+    ctx.profileReset()
+    ctx.profileEnable(dom, True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    dom_ms, dom_launches = ctx.profileRead(dom)
+    ctx.profileEnable(dom, False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_total = F * world * args.steps
+    fps = frames_total / dt
+    m1_total, m2 = state["m1_total"], state["m2"]
+
+    # ---- algorithmic bytes (DESIGN.md "Kernels and rooflines") ----------------------------------------
+    nv = n_valid_total  # valid points of this rank's frames (per step)
+    merge_n = m1_total  # points entering the combined merge on this rank
+    bytes_per_step = {
+        "reproject_count": 1 * n_cand * F,
+        "reproject_emit": 4 * n_cand * F + 16 * nv,
+        "voxel_keys": 20 * (nv + merge_n),
+        "radix_hist": 4 * 4 * (nv + merge_n),                # 4 passes
+        "radix_scatter": (12 + 3 * 16) * (nv + merge_n),    # pass 0 has no value array to read
+        "run_segments": 2 * 4 * (nv + merge_n) + 4 * (m1_total // world + m2),
+        "centroid": 20 * (nv + merge_n) + 16 * (m1_total // world + m2),
+    }
+    dom_name = L.KERNEL_NAMES[dom]
+    achieved = bytes_per_step[dom_name] * args.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2), "launches": int(dom_launches),
+                "algorithmic_bytes_per_launch": int(bytes_per_step[dom_name] * args.steps / max(dom_launches, 1))}
+    traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tj = json.load(open(traffic_file))
+            if tj.get("kernel") == dom_name:
+                roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    # SURVEY 8d end-to-end figure: B_frame = 4N + 16Nv + 16Nv + 16M1 per frame, B_final = 16 SUM(M1) + 16 M2
+    b_frame = (4 * n_cand * F + 32 * nv + 16 * (m1_total // world)) / F
+    b_final = 16 * merge_n + 16 * m2
+    e2e_gbs = (b_frame * F + b_final) * args.steps * world / dt / 1e9
+
+    result = {
+        "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.cols}x{args.rows} dense stereo, jump_pixels {args.jump_pixels}, "
+                               f"{F} frames/GPU, voxel_size {args.voxel_size}, min_points_per_voxel {args.min_points}, "
+                               "SOR off, frames resident in HBM (BASELINE.json configs[1])",
+                   "frames_per_gpu": F, "rows": args.rows, "cols": args.cols, "jump_pixels": args.jump_pixels,
+                   "voxel_size": args.voxel_size, "parallelism": f"frame-sharded x{world}"},
+        "mpoints_per_sec_into_global_cloud": round(m1_total * args.steps / dt / 1e6, 2),
+        "points": {"candidates_per_frame": n_cand, "valid_per_step_per_gpu": nv, "per_frame_voxels_total": m1_total,
+                   "merged_cells": m2},
+        "roofline": roofline,
+        "end_to_end": {"algorithmic_GBps": round(e2e_gbs, 2), "frac_of_hbm_peak": round(e2e_gbs / HBM_PEAK_GBS / world, 5),
+                       "bytes_per_frame": int(b_frame), "bytes_final_merge": int(b_final)},
+        "kernel_ms_per_step": {k: round(v[0], 3) for k, v in per_kernel.items()},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nf = min(args.cpu_frames, F)
+        v7, t7 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, args.cpu_threads, nf)
+        n1 = min(8, F)
+        v1, t1 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, 1, n1)
+        result["cpu_baseline"] = {"value": round(v7, 3), "unit": "frames/s", "cores": args.cpu_threads, "kind": "port",
+                                  "sample": f"first {nf} frames of the same workload through the C oracle (A6 per frame on "
+                                            f"{args.cpu_threads} frame-parallel threads as pose.cpp:392-413, then the combined "
+                                            f"merge), {t7:.1f} s; single thread: {v1:.3f} frames/s on {n1} frames",
+                                  "single_thread_value": round(v1, 3), "host_cores": os.cpu_count()}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,14 @@ def load_library():
         if not os.path.exists(_LIB):
             raise O3drError(ERR_NO_DEVICE, f"{_LIB} is not built: run `python __graft_entry__.py` or `make` "
                                            "(there is no CPU fallback)")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  A process must hold ONE HIP/HSA
+        # runtime, so when torch is installed it is imported first: libo3dr's DT_NEEDED
+        # libamdhip64.so.7 then binds to the copy torch already loaded instead of /opt/rocm's
+        # (loading both leaves the second one with "No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIB)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the export is missing
