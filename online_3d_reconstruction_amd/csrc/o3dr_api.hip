@@ -60,7 +60,7 @@ struct o3dr_ctx {
     size_t ws_elems = 0;   // frames*(cap+1) the per-point arrays were allocated for
     size_t ws_pts_elems = 0;
     int ws_frames = 0;
-    size_t ws_emit_tiles = 0, ws_sort_tiles = 0, ws_seg_tiles = 0;
+    size_t ws_emit_tiles = 0, ws_sort_tiles = 0, ws_seg_tiles = 0, ws_mm_floats = 0;
     DevBuf ws_block, ws_pts_block;
 
     // accumulating cloud (pose.cpp:434 cloud_big)
@@ -114,8 +114,13 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
     const size_t emit_tiles = (size_t)frames * (size_t)((cap + kEmitTile - 1) / kEmitTile);
     const size_t sort_tiles = (size_t)frames * (size_t)((cap + kSortTile - 1) / kSortTile);
     const size_t seg_tiles = (size_t)frames * (size_t)((cap + kSegTile - 1) / kSegTile);
+    // bounding-box slots per frame: one per reprojection tile + the keypoint slot, or kMinmaxBlocks
+    size_t mm_slots = (size_t)((cap + kEmitTile - 1) / kEmitTile) + 1;
+    if (mm_slots < (size_t)kMinmaxBlocks) mm_slots = kMinmaxBlocks;
+    const size_t mm_floats = (size_t)frames * mm_slots * 6;
     if (elems > c->ws_elems || frames > c->ws_frames || emit_tiles > c->ws_emit_tiles ||
-        sort_tiles > c->ws_sort_tiles || seg_tiles > c->ws_seg_tiles) {
+        sort_tiles > c->ws_sort_tiles || seg_tiles > c->ws_seg_tiles || mm_floats > c->ws_mm_floats) {
+        const size_t MM = mm_floats > c->ws_mm_floats ? mm_floats : c->ws_mm_floats;
         const size_t E = elems > c->ws_elems ? elems : c->ws_elems;
         const int F = frames > c->ws_frames ? frames : c->ws_frames;
         const size_t TE = emit_tiles > c->ws_emit_tiles ? emit_tiles : c->ws_emit_tiles;
@@ -130,7 +135,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_tile = off;  off += align256(TE * 4);
         size_t o_hist = off;  off += align256(TS * kRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
-        size_t o_mm = off;    off += align256((size_t)F * 6 * 4);
+        size_t o_part = off;  off += align256(((TS * kRadix + TG + TE) / 4096 + 4 * (size_t)F + 16) * 4);
+        size_t o_mm = off;    off += align256(MM * 4);
         size_t o_nv = off;    off += align256((size_t)F * 4);
         size_t o_nk = off;    off += align256((size_t)F * 4);
         size_t o_nx = off;    off += align256((size_t)F * 4);
@@ -149,7 +155,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
-        w.minmax = (uint32_t*)(base + o_mm);
+        w.scan_partial = (uint32_t*)(base + o_part);
+        w.mm = (float*)(base + o_mm);
         w.n_valid = (uint32_t*)(base + o_nv);
         w.n_kp = (uint32_t*)(base + o_nk);
         w.n_vox = (uint32_t*)(base + o_nx);
@@ -162,7 +169,9 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         c->ws_emit_tiles = TE;
         c->ws_sort_tiles = TS;
         c->ws_seg_tiles = TG;
+        c->ws_mm_floats = MM;
     }
+    c->ws.mm_stride = (int64_t)mm_slots;
     if (need_pts) {
         const size_t pe = (size_t)frames * (size_t)cap;
         if (pe > c->ws_pts_elems) {
@@ -358,6 +367,7 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
     memcpy(a.Q, c->Q, sizeof a.Q);
     a.min_disp = c->params.min_disparity;
     a.out_fstride = out_fstride;
+    a.mm_stride = c->ws.mm_stride;
 }
 
 // stage a host buffer into HBM (or pass a device pointer through)
@@ -399,10 +409,11 @@ static int run_reproject_single(o3dr_ctx* c, const uint8_t* disp_d, int64_t disp
         a.xf_mode = 1;
         for (int i = 0; i < 12; ++i) a.T[i] = T[i];
     }
-    launch_minmax_init(&c->prof, c->stream, c->ws.minmax, c->ws.n_kp, 1);
+    launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, 1);
     if (c->params.jump_pixels != 1 && n_kp > 0)
-        launch_keypoint_pass(&c->prof, c->stream, a, kp_d, n_kp, dst, c->ws.n_kp, c->ws.minmax);
-    launch_reproject(&c->prof, c->stream, a, 1, dst, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.minmax);
+        launch_keypoint_pass(&c->prof, c->stream, a, kp_d, n_kp, dst, c->ws.n_kp, c->ws.mm);
+    launch_reproject(&c->prof, c->stream, a, 1, dst, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
+                     c->ws.scan_partial);
     HIPCHK(hipGetLastError());
     return O3DR_OK;
 }
@@ -470,6 +481,7 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
         v.out_base = final_dst;
         v.cc = c->cc_tmp;
         v.passthrough = 0;
+        v.mm_used = (int)((g.n + kEmitTile - 1) / kEmitTile) + 1;
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         CloudCounters cc;
@@ -551,8 +563,7 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
 {
     CHK(ws_ensure(c, 1, n_in, false));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
-    launch_minmax_init(&c->prof, c->stream, c->ws.minmax, nullptr, 1);
-    launch_points_minmax(&c->prof, c->stream, in_d, 0, c->ws.n_valid, 1, n_in, c->ws.minmax);
+    const int mm_used = launch_points_minmax(&c->prof, c->stream, in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
     CHK(zero_counters(c, c->cc_tmp));
     VoxelArgs v;
     v.in = in_d;
@@ -568,6 +579,7 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     v.out_base = out_d;
     v.cc = c->cc_tmp;
     v.passthrough = 0;
+    v.mm_used = mm_used;
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     CloudCounters cc;
@@ -751,7 +763,7 @@ extern "C" int o3dr_cloud_big_append(o3dr_ctx* c, const o3dr_point* pts, int64_t
     v.out_base = c->cloud_big;
     v.cc = c->cc_big;
     v.passthrough = 1;
-    launch_minmax_init(&c->prof, c->stream, c->ws.minmax, nullptr, 1);
+    v.mm_used = 0;
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     c->cloud_ub += n;
@@ -802,8 +814,9 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
                   bgr_frame_stride, rows, cols, g, g.n);
         a.xf_mode = 2;
         a.poses = (const float*)poses_d;
-        launch_minmax_init(&c->prof, c->stream, c->ws.minmax, c->ws.n_kp, nb);
-        launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.minmax);
+        launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
+        launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
+                     c->ws.scan_partial);
         VoxelArgs v;
         v.in = c->ws.pts;
         v.in_fstride = g.n;
@@ -818,6 +831,7 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         v.out_base = c->cloud_big;
         v.cc = c->cc_big;
         v.passthrough = c->params.dont_downsample ? 1 : 0;
+        v.mm_used = a.n_tiles + 1;
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         c->cloud_ub += (int64_t)nb * g.n;

@@ -25,6 +25,7 @@ constexpr int kRadix = 1 << kRadixBits;
 // generic per-point kernels
 constexpr int kPtThreads = 256;
 constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head kernels
+constexpr int kMinmaxBlocks = 1024;  // workgroups (= bounding-box slots) of the stand-alone min/max pass
 
 // ---- per-frame voxel grid geometry (PCL VoxelGrid members), written by k_voxel_geom -----------
 struct VoxelGeom {
@@ -51,6 +52,7 @@ struct ReprojectArgs {
     double Q[16];
     double min_disp;
     int64_t out_fstride;  // points between consecutive frames' output regions
+    int64_t mm_stride;    // bounding-box slots per frame
 };
 
 // All per-batch device buffers.  Sizes are for `frames` frames of at most `cap` points each.
@@ -65,8 +67,10 @@ struct Workspace {
     uint32_t* tile_cnt = nullptr;  // frames*n_emit_tiles
     uint32_t* hist = nullptr;      // frames*kRadix*n_sort_tiles
     uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
+    uint32_t* scan_partial = nullptr;  // chunk sums of the multi-workgroup scan
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
-    uint32_t* minmax = nullptr;    // frames*6   order-preserving uint encoding of fp32 min/max
+    float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
+    int64_t mm_stride = 0;         // slots per frame
     uint32_t* n_valid = nullptr;   // frames     points per frame after A1
     uint32_t* n_kp = nullptr;      // frames     keypoint-pass points (single-frame API), else 0
     uint32_t* n_vox = nullptr;     // frames     voxel runs
@@ -86,15 +90,16 @@ struct CloudCounters {
 // ---- launchers (o3dr_kernels.hip).  All are asynchronous on `s`. -------------------------------
 struct Profiler;  // o3dr_api.hip
 
-void launch_minmax_init(Profiler* pf, hipStream_t s, uint32_t* minmax, uint32_t* n_kp, int frames);
+void launch_minmax_init(Profiler* pf, hipStream_t s, float* mm, int64_t mm_stride, int slot, uint32_t* n_kp, int frames);
 void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,
-                          o3dr_point* out, uint32_t* n_kp_out, uint32_t* minmax);
+                          o3dr_point* out, uint32_t* n_kp_out, float* mm);
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
-                      uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, uint32_t* minmax);
+                      uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, float* mm,
+                      uint32_t* scan_partial);
 void launch_transform(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t n, const float* T16_host,
                       o3dr_point* out);
-void launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
-                          const uint32_t* n_dev, int frames, int64_t cap, uint32_t* minmax);
+int launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
+                         const uint32_t* n_dev, int frames, int64_t cap, int64_t mm_stride, float* mm);
 // voxel grid over `frames` independent clouds (cloud f = in + f*in_fstride, n_dev[f] points);
 // results are appended at out_base[cc->count + ...] in frame order and cc->count is advanced.
 struct VoxelArgs {
@@ -109,6 +114,7 @@ struct VoxelArgs {
     o3dr_point* out_base;
     CloudCounters* cc;
     int passthrough;  // dont_downsample: append the input unchanged
+    int mm_used;      // bounding-box slots to fold per frame
 };
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);

@@ -19,16 +19,6 @@ namespace o3dr {
 // =================================================================================================
 // small device helpers
 // =================================================================================================
-__device__ __forceinline__ uint32_t f32_ordered(float f)
-{  // order-preserving map fp32 -> uint32 (for atomicMin/atomicMax)
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ordered_f32(uint32_t e)
-{
-    const uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
-    return __uint_as_float(u);
-}
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
     const int lane = threadIdx.x & 63;
@@ -82,10 +72,11 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* ld
     __syncthreads();
     return r;
 }
-// workgroup min/max of per-thread (lo[3], hi[3]) -> atomics on the frame's ordered-uint slots
+// workgroup min/max of per-thread (lo[3], hi[3]) -> one 6-float slot (min xyz, max xyz); a workgroup
+// without points stores (+inf, -inf).  Slots are reduced by k_voxel_geom: no same-address atomics.
 template <int NW>
-__device__ __forceinline__ void block_minmax_atomic(const float lo[3], const float hi[3], bool any,
-                                                    float* lds /*6*NW*/, uint32_t* mm6)
+__device__ __forceinline__ void block_minmax_store(const float lo[3], const float hi[3], bool any,
+                                                   float* lds /*6*NW*/, float* __restrict__ slot6)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -103,11 +94,7 @@ __device__ __forceinline__ void block_minmax_atomic(const float lo[3], const flo
         float v = lds[a];
 #pragma unroll
         for (int i = 1; i < NW; ++i) v = (a < 3) ? fminf(v, lds[i * 6 + a]) : fmaxf(v, lds[i * 6 + a]);
-        if (a < 3) {
-            if (v != __builtin_inff()) atomicMin(&mm6[a], f32_ordered(v));
-        } else {
-            if (v != -__builtin_inff()) atomicMax(&mm6[a], f32_ordered(v));
-        }
+        slot6[a] = v;
     }
     __syncthreads();
 }
@@ -208,7 +195,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_count(ReprojectArgs 
 __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a, o3dr_point* __restrict__ out,
                                                                  const uint32_t* __restrict__ tile_off,
                                                                  const uint32_t* __restrict__ n_kp,
-                                                                 uint32_t* __restrict__ minmax)
+                                                                 float* __restrict__ mm)
 {
     __shared__ uint4 stage[kEmitTile];  // 16 KiB: the tile's points in output order
     __shared__ uint32_t scan_lds[kEmitThreads / 64 + 1];
@@ -283,13 +270,13 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(out + (int64_t)f * a.out_fstride + n_kp[f] + tile_off[(int64_t)f * a.n_tiles + tile]);
     for (uint32_t i = threadIdx.x; i < total; i += kEmitThreads) dst[i] = stage[i];
-    block_minmax_atomic<kEmitThreads / 64>(lo, hi, valid != 0, mm_lds, minmax + 6 * f);
+    block_minmax_store<kEmitThreads / 64>(lo, hi, valid != 0, mm_lds, mm + ((int64_t)f * a.mm_stride + tile) * 6);
 }
 
 // keypoint pass (pose_functions.cpp:1057-1091): one workgroup walks the keypoints in order
 __global__ __launch_bounds__(256) void k_keypoint_pass(ReprojectArgs a, const float* __restrict__ kp_xy, int n_kp,
                                                        o3dr_point* __restrict__ out, uint32_t* __restrict__ n_kp_out,
-                                                       uint32_t* __restrict__ minmax)
+                                                       float* __restrict__ mm)
 {
     __shared__ uint32_t scan_lds[256 / 64 + 1];
     __shared__ float mm_lds[6 * 4];
@@ -329,7 +316,7 @@ __global__ __launch_bounds__(256) void k_keypoint_pass(ReprojectArgs a, const fl
         base += total;
     }
     if (threadIdx.x == 0) n_kp_out[0] = base;
-    block_minmax_atomic<4>(lo, hi, any, mm_lds, minmax);
+    block_minmax_store<4>(lo, hi, any, mm_lds, mm + (int64_t)a.n_tiles * 6);  // slot after the grid tiles
 }
 
 // A2 alone: pcl::transformPointCloud on an existing cloud (also the in-place re-transform of
@@ -354,10 +341,14 @@ __global__ __launch_bounds__(kPtThreads) void k_transform(const o3dr_point* __re
 // =================================================================================================
 // small bookkeeping kernels
 // =================================================================================================
-__global__ void k_minmax_init(uint32_t* minmax, uint32_t* n_kp, int frames)
+// neutral bounding-box slot `slot` of every frame (the keypoint-pass slot when there is no keypoint pass)
+__global__ void k_minmax_init(float* mm, int64_t mm_stride, int slot, uint32_t* n_kp, int frames)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < frames * 6) minmax[i] = (i % 6 < 3) ? 0xffffffffu : 0u;
+    if (i < frames * 6) {
+        const int f = i / 6, a = i % 6;
+        mm[((int64_t)f * mm_stride + slot) * 6 + a] = (a < 3) ? __builtin_inff() : -__builtin_inff();
+    }
     if (n_kp && i < frames) n_kp[i] = 0;
 }
 __global__ void k_set_counts(uint32_t* n_dev, uint32_t value, int frames)
@@ -389,12 +380,52 @@ __global__ __launch_bounds__(1024) void k_scan_rows(uint32_t* __restrict__ data,
     if (totals && threadIdx.x == 0) totals[blockIdx.x] = total + (add ? add[blockIdx.x] : 0u);
 }
 
+// Multi-workgroup form for long rows (radix histograms, big merges): chunk sums -> k_scan_rows over
+// the chunk sums -> per-chunk scan with the chunk's base.  A chunk is 4096 words, 16 per lane.
+constexpr int kScanChunk = 4096;
+__global__ __launch_bounds__(256) void k_scan_chunk_sums(const uint32_t* __restrict__ data, int64_t L, int64_t row_stride,
+                                                         int n_chunks, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t lds[4];
+    const uint32_t* row = data + (int64_t)blockIdx.y * row_stride;
+    const int64_t b = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 16;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (b + k < L) s += row[b + k];
+    s = wave_sum_u32(s);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * n_chunks + blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+__global__ __launch_bounds__(256) void k_scan_chunk_apply(uint32_t* __restrict__ data, int64_t L, int64_t row_stride,
+                                                          int n_chunks, const uint32_t* __restrict__ partial_scanned)
+{
+    __shared__ uint32_t lds[5];
+    uint32_t* row = data + (int64_t)blockIdx.y * row_stride;
+    const int64_t b = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 16;
+    uint32_t v[16];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = (b + k < L) ? row[b + k] : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan_u32<4>(s, lds, total) + partial_scanned[(int64_t)blockIdx.y * n_chunks + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (b + k < L) row[b + k] = run;
+        run += v[k];
+    }
+}
+
 // fp32 min/max of arbitrary clouds (stand-alone voxel grid calls; the fused path gets its
 // bounding box from k_reproject_emit).  The `z += 500` of the combined mode (pose_functions.cpp:1666)
 // is applied to the box afterwards by k_voxel_geom: fp32 addition is monotonic.
 __global__ __launch_bounds__(kPtThreads) void k_points_minmax(const o3dr_point* __restrict__ in, int64_t in_fstride,
-                                                              const uint32_t* __restrict__ n_dev,
-                                                              uint32_t* __restrict__ minmax)
+                                                              const uint32_t* __restrict__ n_dev, int64_t mm_stride,
+                                                              float* __restrict__ mm)
 {
     __shared__ float mm_lds[6 * (kPtThreads / 64)];
     const int f = blockIdx.y;
@@ -403,33 +434,55 @@ __global__ __launch_bounds__(kPtThreads) void k_points_minmax(const o3dr_point* 
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     bool any = false;
-    const int64_t base = (int64_t)blockIdx.x * (kPtThreads * 8);
-    if (base >= n) return;
+    const int64_t stride = (int64_t)gridDim.x * (kPtThreads * 4);
+    for (int64_t base = (int64_t)blockIdx.x * (kPtThreads * 4); base < n; base += stride) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int64_t i = base + k * kPtThreads + threadIdx.x;
-        if (i < n) {
-            const uint4 v = src[i];
-            const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z);
-            lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
-            lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
-            lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
-            any = true;
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = base + k * kPtThreads + threadIdx.x;
+            if (i < n) {
+                const uint4 v = src[i];
+                const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z);
+                lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+                lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+                lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+                any = true;
+            }
         }
     }
-    block_minmax_atomic<kPtThreads / 64>(lo, hi, any, mm_lds, minmax + 6 * f);
+    block_minmax_store<kPtThreads / 64>(lo, hi, any, mm_lds, mm + ((int64_t)f * mm_stride + blockIdx.x) * 6);
 }
 
 // =================================================================================================
 // K2a — PCL VoxelGrid geometry and per-point linear index
 //   [PCL 1.8 filters/impl/voxel_grid.hpp applyFilter; called from pose_functions.cpp:1689-1700]
 // =================================================================================================
-__global__ void k_voxel_geom(const uint32_t* __restrict__ minmax, const uint32_t* __restrict__ n_dev, int frames,
-                             float leaf0, float leaf1, float leaf2, float z_offset,
-                             VoxelGeom* __restrict__ geom)
+__global__ __launch_bounds__(256) void k_voxel_geom(const float* __restrict__ mm, int64_t mm_stride, int mm_used,
+                                                    const uint32_t* __restrict__ n_dev, float leaf0, float leaf1,
+                                                    float leaf2, float z_offset, VoxelGeom* __restrict__ geom)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= frames) return;
+    __shared__ float red[6 * 4];
+    const int f = blockIdx.x;
+    // getMinMax3D: fold the per-workgroup boxes of this frame (min/max are order independent)
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    const float* row = mm + (int64_t)f * mm_stride * 6;
+    for (int sidx = threadIdx.x; sidx < mm_used; sidx += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], row[sidx * 6 + a]);
+            hi[a] = fmaxf(hi[a], row[sidx * 6 + 3 + a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_min_f32(lo[a]), h = wave_max_f32(hi[a]);
+        if ((threadIdx.x & 63) == 0) {
+            red[(threadIdx.x >> 6) * 6 + a] = l;
+            red[(threadIdx.x >> 6) * 6 + 3 + a] = h;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     VoxelGeom g;
     const float leaf[3] = {leaf0, leaf1, leaf2};
     g.n = n_dev[f];
@@ -437,8 +490,8 @@ __global__ void k_voxel_geom(const uint32_t* __restrict__ minmax, const uint32_t
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
         g.inv[a] = 1.0f / leaf[a];  // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
-        mn[a] = ordered_f32(minmax[6 * f + a]);
-        mx[a] = ordered_f32(minmax[6 * f + 3 + a]);
+        mn[a] = fminf(fminf(red[a], red[6 + a]), fminf(red[12 + a], red[18 + a]));
+        mx[a] = fmaxf(fmaxf(red[3 + a], red[9 + a]), fmaxf(red[15 + a], red[21 + a]));
     }
     // the bounding box was taken before `z += 500` (pose_functions.cpp:1666); fp32 add is monotonic
     mn[2] = mn[2] + z_offset;
@@ -783,10 +836,24 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
 // =================================================================================================
 static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-void launch_minmax_init(Profiler* pf, hipStream_t s, uint32_t* minmax, uint32_t* n_kp, int frames)
+// exclusive scan of `frames` rows of length L in place; totals[f] = row sum (+ add[f])
+static void launch_scan(hipStream_t s, uint32_t* data, int64_t L, int64_t row_stride, int frames, uint32_t* totals,
+                        const uint32_t* add, uint32_t* partial)
+{
+    if (L <= 2 * kScanChunk) {
+        k_scan_rows<<<frames, 1024, 0, s>>>(data, L, row_stride, totals, add);
+        return;
+    }
+    const int n_chunks = cdiv64(L, kScanChunk);
+    k_scan_chunk_sums<<<dim3(n_chunks, frames), 256, 0, s>>>(data, L, row_stride, n_chunks, partial);
+    k_scan_rows<<<frames, 1024, 0, s>>>(partial, n_chunks, n_chunks, totals, add);
+    k_scan_chunk_apply<<<dim3(n_chunks, frames), 256, 0, s>>>(data, L, row_stride, n_chunks, partial);
+}
+
+void launch_minmax_init(Profiler* pf, hipStream_t s, float* mm, int64_t mm_stride, int slot, uint32_t* n_kp, int frames)
 {
     ProfScope ps(pf, O3DR_K_OTHER, s);
-    k_minmax_init<<<cdiv64(frames * 6, 256), 256, 0, s>>>(minmax, n_kp, frames);
+    k_minmax_init<<<cdiv64(frames * 6, 256), 256, 0, s>>>(mm, mm_stride, slot, n_kp, frames);
 }
 
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames)
@@ -796,14 +863,15 @@ void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t va
 }
 
 void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,
-                          o3dr_point* out, uint32_t* n_kp_out, uint32_t* minmax)
+                          o3dr_point* out, uint32_t* n_kp_out, float* mm)
 {
     ProfScope ps(pf, O3DR_K_OTHER, s);
-    k_keypoint_pass<<<1, 256, 0, s>>>(a, kp_xy, n_kp, out, n_kp_out, minmax);
+    k_keypoint_pass<<<1, 256, 0, s>>>(a, kp_xy, n_kp, out, n_kp_out, mm);
 }
 
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
-                      uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, uint32_t* minmax)
+                      uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, float* mm,
+                      uint32_t* scan_partial)
 {
     if (a.n_tiles <= 0) {  // jump_pixels == 0: keypoints only
         ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -817,11 +885,11 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     }
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
-        k_scan_rows<<<frames, 1024, 0, s>>>(tile_cnt, a.n_tiles, a.n_tiles, n_valid, n_kp);
+        launch_scan(s, tile_cnt, a.n_tiles, a.n_tiles, frames, n_valid, n_kp, scan_partial);
     }
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
-        k_reproject_emit<<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, minmax);
+        k_reproject_emit<<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
     }
 }
 
@@ -835,15 +903,19 @@ void launch_transform(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t
     k_transform<<<cdiv64(n, kPtThreads), kPtThreads, 0, s>>>(in, n, T, out);
 }
 
-void launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
-                          const uint32_t* n_dev, int frames, int64_t cap, uint32_t* minmax)
+int launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
+                         const uint32_t* n_dev, int frames, int64_t cap, int64_t mm_stride, float* mm)
 {
-    if (cap <= 0) return;
+    if (cap <= 0) return 0;
+    int nblk = cdiv64(cap, kPtThreads * 4);
+    if (nblk > kMinmaxBlocks) nblk = kMinmaxBlocks;
     ProfScope ps(pf, O3DR_K_OTHER, s);
-    k_points_minmax<<<dim3(cdiv64(cap, kPtThreads * 8), frames), kPtThreads, 0, s>>>(in, in_fstride, n_dev, minmax);
+    k_points_minmax<<<dim3(nblk, frames), kPtThreads, 0, s>>>(in, in_fstride, n_dev, mm_stride, mm);
+    return nblk;  // slots written per frame
 }
 
-// The voxel grid proper.  Expects ws.minmax to hold the bounding boxes of the (un-offset) inputs.
+// The voxel grid proper.  Expects ws.mm slots [0, v.mm_used) of every frame to hold bounding boxes of
+// the (un-offset) inputs.
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v)
 {
     const int F = v.frames;
@@ -852,8 +924,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     const int n_seg_tiles = cdiv64(cap, kSegTile);
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
-        k_voxel_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.minmax, v.n_dev, F, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset,
-                                                 ws.geom);
+        k_voxel_geom<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, v.mm_used, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2],
+                                       v.z_offset, ws.geom);
     }
     uint32_t* n_keep = nullptr;
     if (!v.passthrough && cap > 0) {
@@ -872,8 +944,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
-                k_scan_rows<<<F, 1024, 0, s>>>(ws.hist, (int64_t)kRadix * n_sort_tiles, (int64_t)kRadix * n_sort_tiles,
-                                              nullptr, nullptr);
+                launch_scan(s, ws.hist, (int64_t)kRadix * n_sort_tiles, (int64_t)kRadix * n_sort_tiles, F, nullptr, nullptr,
+                            ws.scan_partial);
             }
             {
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
@@ -891,7 +963,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         }
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
-            k_scan_rows<<<F, 1024, 0, s>>>(ws.seg_cnt, n_seg_tiles, n_seg_tiles, ws.n_vox, nullptr);
+            launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_vox, nullptr, ws.scan_partial);
         }
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
@@ -906,7 +978,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
-                k_scan_rows<<<F, 1024, 0, s>>>(ws.seg_cnt, n_seg_tiles, n_seg_tiles, ws.n_out, nullptr);
+                launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_out, nullptr, ws.scan_partial);
             }
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
