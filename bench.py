@@ -172,6 +172,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dom_ms, dom_launches = ctx.profileRead(dom)
+    stats = ctx.profileStats()
     ctx.profileEnable(dom, False)
 
     if world > 1:
@@ -183,17 +184,18 @@ def main():
     fps = frames_total / dt
     m1_total, m2 = state["m1_total"], state["m2"]
 
-    # ---- algorithmic bytes (DESIGN.md "Kernels and rooflines") ----------------------------------------
+    # ---- algorithmic bytes per step (DESIGN.md "Kernels and rooflines") --------------------------------
+    rec_passes, vox_in, vox_out = (v / args.steps for v in stats)  # device counters over the timed region
     nv = n_valid_total  # valid points of this rank's frames (per step)
     merge_n = m1_total  # points entering the combined merge on this rank
     bytes_per_step = {
-        "reproject_count": 1 * n_cand * F,
-        "reproject_emit": 4 * n_cand * F + 16 * nv,
-        "voxel_keys": 20 * (nv + merge_n),
-        "radix_hist": 4 * 4 * (nv + merge_n),                # 4 passes
-        "radix_scatter": (12 + 3 * 16) * (nv + merge_n),    # pass 0 has no value array to read
-        "run_segments": 2 * 4 * (nv + merge_n) + 4 * (m1_total // world + m2),
-        "centroid": 20 * (nv + merge_n) + 16 * (m1_total // world + m2),
+        "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate
+        "reproject_emit": 4 * n_cand * F + 16 * nv,            # 1 B disparity + 3 B colour in, 16 B point out
+        "voxel_keys": 20 * vox_in,                             # 16 B point in, 4 B index out
+        "radix_hist": 4 * rec_passes,                          # 4 B index per record per pass
+        "radix_scatter": 16 * rec_passes - 4 * vox_in,         # (index,id) in and out; pass 0 has no id to read
+        "run_segments": 8 * vox_in + 4 * vox_out,              # index read twice, run starts written
+        "centroid": 20 * vox_in + 16 * vox_out,                # id + gathered point in, centroid out
     }
     dom_name = L.KERNEL_NAMES[dom]
     achieved = bytes_per_step[dom_name] * args.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

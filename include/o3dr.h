@@ -204,6 +204,10 @@ int o3dr_profile_enable(o3dr_ctx* ctx, int32_t kernel_id, int32_t enable);
 /* Synchronises; total milliseconds and launch count of `kernel_id` since enable/reset. */
 int o3dr_profile_read(o3dr_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
 int o3dr_profile_reset(o3dr_ctx* ctx);
+/* Synchronises; counters since the last o3dr_profile_reset, for algorithmic-byte accounting:
+ * out[0] = sum over voxel grids of (points x radix passes actually run), out[1] = points that entered
+ * voxel grids, out[2] = points that left them, out[3] = 0. */
+int o3dr_profile_stats(o3dr_ctx* ctx, int64_t out[4]);
 /* device name / arch / CU count of the context's device, for bench headers */
 int o3dr_device_info(o3dr_ctx* ctx, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
 

@@ -292,6 +292,12 @@ class Context:
     def profileReset(self):
         L.check(self._lib.o3dr_profile_reset(self._h))
 
+    def profileStats(self):
+        """(sort record-passes, voxel-grid points in, voxel-grid points out) since profileReset()"""
+        out = (C.c_int64 * 4)()
+        L.check(self._lib.o3dr_profile_stats(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def profileRead(self, kernel_id):
         ms = C.c_double(0)
         n = C.c_int64(0)

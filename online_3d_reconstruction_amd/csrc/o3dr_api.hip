@@ -71,6 +71,8 @@ struct o3dr_ctx {
     CloudCounters* cc_tmp = nullptr;   // device, for single-shot calls
     CloudCounters* cc_host = nullptr;  // pinned
     uint32_t* n_host = nullptr;        // pinned scratch (4 words)
+    SortStats* stats_dev = nullptr;    // device statistics (bench.py byte accounting)
+    SortStats* stats_host = nullptr;   // pinned
 
     DevBuf st_disp, st_bgr, st_in, st_out, st_kp, st_poses;
     Profiler prof;
@@ -132,10 +134,11 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_vals0 = off; off += align256(E * 4);
         size_t o_vals1 = off; off += align256(E * 4);
         size_t o_seg = off;   off += align256(E * 4);
+        size_t o_keep = off;  off += align256(E * 4);
         size_t o_tile = off;  off += align256(TE * 4);
-        size_t o_hist = off;  off += align256(TS * kRadix * 4);
+        size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
-        size_t o_part = off;  off += align256(((TS * kRadix + TG + TE) / 4096 + 4 * (size_t)F + 16) * 4);
+        size_t o_part = off;  off += align256(((TS * kMaxRadix + TG + TE) / 4096 + 4 * (size_t)F + 16) * 4);
         size_t o_mm = off;    off += align256(MM * 4);
         size_t o_nv = off;    off += align256((size_t)F * 4);
         size_t o_nk = off;    off += align256((size_t)F * 4);
@@ -151,7 +154,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.vals[0] = (uint32_t*)(base + o_vals0);
         w.vals[1] = (uint32_t*)(base + o_vals1);
         w.seg_start = (uint32_t*)(base + o_seg);
-        w.keep_idx = w.keys[1];  // free once the 4-pass sort has landed back in buffer 0
+        w.keep_idx = (uint32_t*)(base + o_keep);
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
@@ -223,12 +226,15 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (hipMalloc((void**)&c->cc_big, sizeof(CloudCounters)) != hipSuccess ||
         hipMalloc((void**)&c->cc_tmp, sizeof(CloudCounters)) != hipSuccess ||
         hipHostMalloc((void**)&c->cc_host, sizeof(CloudCounters), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->n_host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&c->n_host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&c->stats_dev, sizeof(SortStats)) != hipSuccess ||
+        hipHostMalloc((void**)&c->stats_host, sizeof(SortStats), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(O3DR_ERR_ALLOC, "counter allocation failed");
     }
     (void)hipMemsetAsync(c->cc_big, 0, sizeof(CloudCounters), c->stream);
     (void)hipMemsetAsync(c->cc_tmp, 0, sizeof(CloudCounters), c->stream);
+    (void)hipMemsetAsync(c->stats_dev, 0, sizeof(SortStats), c->stream);
     const char* env = getenv("O3DR_BATCH_FRAMES");
     if (env && atoi(env) > 0) c->max_batch = atoi(env) > 64 ? 64 : atoi(env);
     *out_ctx = c;
@@ -253,6 +259,8 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->cc_tmp) (void)hipFree(c->cc_tmp);
     if (c->cc_host) (void)hipHostFree(c->cc_host);
     if (c->n_host) (void)hipHostFree(c->n_host);
+    if (c->stats_dev) (void)hipFree(c->stats_dev);
+    if (c->stats_host) (void)hipHostFree(c->stats_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return O3DR_OK;
@@ -482,6 +490,7 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
         v.cc = c->cc_tmp;
         v.passthrough = 0;
         v.mm_used = (int)((g.n + kEmitTile - 1) / kEmitTile) + 1;
+        v.stats = c->stats_dev;
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         CloudCounters cc;
@@ -580,6 +589,7 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     v.cc = c->cc_tmp;
     v.passthrough = 0;
     v.mm_used = mm_used;
+    v.stats = c->stats_dev;
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     CloudCounters cc;
@@ -764,6 +774,7 @@ extern "C" int o3dr_cloud_big_append(o3dr_ctx* c, const o3dr_point* pts, int64_t
     v.cc = c->cc_big;
     v.passthrough = 1;
     v.mm_used = 0;
+    v.stats = nullptr;
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     c->cloud_ub += n;
@@ -832,6 +843,7 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         v.cc = c->cc_big;
         v.passthrough = c->params.dont_downsample ? 1 : 0;
         v.mm_used = a.n_tiles + 1;
+        v.stats = c->stats_dev;
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         c->cloud_ub += (int64_t)nb * g.n;
@@ -911,8 +923,21 @@ extern "C" int o3dr_profile_read(o3dr_ctx* c, int32_t kernel_id, double* total_m
 extern "C" int o3dr_profile_reset(o3dr_ctx* c)
 {
     CTX_ENTER(c);
+    HIPCHK(hipMemsetAsync(c->stats_dev, 0, sizeof(SortStats), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->prof.reset();
+    return O3DR_OK;
+}
+extern "C" int o3dr_profile_stats(o3dr_ctx* c, int64_t out[4])
+{
+    CTX_ENTER(c);
+    if (!out) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
+    HIPCHK(hipMemcpyAsync(c->stats_host, c->stats_dev, sizeof(SortStats), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    out[0] = (int64_t)c->stats_host->sort_record_passes;
+    out[1] = (int64_t)c->stats_host->voxel_points_in;
+    out[2] = (int64_t)c->stats_host->voxel_points_out;
+    out[3] = 0;
     return O3DR_OK;
 }
 extern "C" int o3dr_device_info(o3dr_ctx* c, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes)

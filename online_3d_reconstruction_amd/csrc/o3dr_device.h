@@ -20,8 +20,9 @@ constexpr int kSortThreads = kSortWaves * kWave;
 constexpr int kSortRounds = 16;
 constexpr int kSortWaveItems = kSortRounds * kWave;
 constexpr int kSortTile = kSortWaves * kSortWaveItems;
-constexpr int kRadixBits = 8;
-constexpr int kRadix = 1 << kRadixBits;
+constexpr int kMaxRadixBits = 10;          // digits are 1..10 bits wide, chosen per frame (k_voxel_geom)
+constexpr int kMaxRadix = 1 << kMaxRadixBits;
+constexpr int kMaxPasses = 4;
 // generic per-point kernels
 constexpr int kPtThreads = 256;
 constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head kernels
@@ -35,6 +36,8 @@ struct VoxelGeom {
     uint32_t mul1, mul2;  // divb_mul_[1], divb_mul_[2]
     uint32_t overflow;    // dx*dy*dz > INT32_MAX  -> output = input
     uint32_t n;           // points in this frame
+    uint32_t passes;      // radix passes this frame's index needs (0 when overflow)
+    uint32_t bpp;         // bits per pass
 };
 
 // ---- arguments of the fused reprojection kernels (A1 + A2) ------------------------------------
@@ -65,7 +68,7 @@ struct Workspace {
     uint32_t* vals[2] = {nullptr, nullptr};  // frames*cap ping-pong
     uint32_t* seg_start = nullptr; // frames*(cap+1)   start of each voxel run in the sorted order
     uint32_t* tile_cnt = nullptr;  // frames*n_emit_tiles
-    uint32_t* hist = nullptr;      // frames*kRadix*n_sort_tiles
+    uint32_t* hist = nullptr;      // frames*kMaxRadix*n_sort_tiles
     uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
     uint32_t* scan_partial = nullptr;  // chunk sums of the multi-workgroup scan
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
@@ -78,6 +81,14 @@ struct Workspace {
     uint64_t* out_off = nullptr;   // frames     absolute output offset of each frame
     VoxelGeom* geom = nullptr;     // frames
     size_t bytes = 0;
+};
+
+// device-resident statistics for bench.py's byte accounting
+struct SortStats {
+    uint64_t sort_record_passes;  // sum over voxel jobs of points * radix passes
+    uint64_t voxel_points_in;     // points entering voxel grids (not counting overflow/passthrough)
+    uint64_t voxel_points_out;    // points leaving them
+    uint64_t pad;
 };
 
 // device-resident counters of the accumulating cloud
@@ -115,6 +126,7 @@ struct VoxelArgs {
     CloudCounters* cc;
     int passthrough;  // dont_downsample: append the input unchanged
     int mm_used;      // bounding-box slots to fold per frame
+    SortStats* stats; // optional device statistics
 };
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);

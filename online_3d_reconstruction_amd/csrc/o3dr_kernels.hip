@@ -359,12 +359,26 @@ __global__ void k_set_counts(uint32_t* n_dev, uint32_t value, int frames)
 
 // Exclusive scan of `frames` independent rows of length L (row f at data + f*row_stride), in place.
 // One 1024-thread workgroup per row; each thread owns a contiguous chunk.  totals[f] (optional)
-// receives the row sum plus add[f] (optional).
-__global__ __launch_bounds__(1024) void k_scan_rows(uint32_t* __restrict__ data, int64_t L, int64_t row_stride,
-                                                    uint32_t* __restrict__ totals, const uint32_t* __restrict__ add)
+// receives the row sum plus add[f] (optional).  With `geom` the row is a radix histogram of pass
+// `pass`: its live length is bins(f)*n_tiles, or nothing when that frame skips the pass.
+__device__ __forceinline__ int64_t scan_row_len(const VoxelGeom* __restrict__ geom, int f, int pass, int n_tiles,
+                                                int64_t L)
+{
+    if (!geom) return L;
+    const VoxelGeom g = geom[f];
+    if (g.overflow || pass >= (int)g.passes) return 0;
+    return ((int64_t)1 << g.bpp) * n_tiles;
+}
+__global__ __launch_bounds__(1024) void k_scan_rows(uint32_t* __restrict__ data, int64_t L_in, int64_t row_stride,
+                                                    uint32_t* __restrict__ totals, const uint32_t* __restrict__ add,
+                                                    const VoxelGeom* __restrict__ geom, int pass, int n_tiles,
+                                                    int chunked)
 {
     __shared__ uint32_t lds[1024 / 64 + 1];
     uint32_t* row = data + (int64_t)blockIdx.x * row_stride;
+    int64_t L = scan_row_len(geom, blockIdx.x, pass, n_tiles, L_in);
+    if (chunked) L = (L + 4095) / 4096;  // scanning the chunk sums of a chunked scan
+    if (L == 0 && !totals) return;
     const int64_t chunk = (L + 1023) / 1024;
     const int64_t b = (int64_t)threadIdx.x * chunk;
     const int64_t e = (b + chunk < L) ? b + chunk : L;
@@ -383,10 +397,14 @@ __global__ __launch_bounds__(1024) void k_scan_rows(uint32_t* __restrict__ data,
 // Multi-workgroup form for long rows (radix histograms, big merges): chunk sums -> k_scan_rows over
 // the chunk sums -> per-chunk scan with the chunk's base.  A chunk is 4096 words, 16 per lane.
 constexpr int kScanChunk = 4096;
-__global__ __launch_bounds__(256) void k_scan_chunk_sums(const uint32_t* __restrict__ data, int64_t L, int64_t row_stride,
-                                                         int n_chunks, uint32_t* __restrict__ partial)
+__global__ __launch_bounds__(256) void k_scan_chunk_sums(const uint32_t* __restrict__ data, int64_t L_in,
+                                                         int64_t row_stride, int n_chunks,
+                                                         uint32_t* __restrict__ partial,
+                                                         const VoxelGeom* __restrict__ geom, int pass, int n_tiles)
 {
     __shared__ uint32_t lds[4];
+    const int64_t L = scan_row_len(geom, blockIdx.y, pass, n_tiles, L_in);
+    if ((int64_t)blockIdx.x * kScanChunk >= L) return;
     const uint32_t* row = data + (int64_t)blockIdx.y * row_stride;
     const int64_t b = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 16;
     uint32_t s = 0;
@@ -398,10 +416,13 @@ __global__ __launch_bounds__(256) void k_scan_chunk_sums(const uint32_t* __restr
     __syncthreads();
     if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * n_chunks + blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
-__global__ __launch_bounds__(256) void k_scan_chunk_apply(uint32_t* __restrict__ data, int64_t L, int64_t row_stride,
-                                                          int n_chunks, const uint32_t* __restrict__ partial_scanned)
+__global__ __launch_bounds__(256) void k_scan_chunk_apply(uint32_t* __restrict__ data, int64_t L_in, int64_t row_stride,
+                                                          int n_chunks, const uint32_t* __restrict__ partial_scanned,
+                                                          const VoxelGeom* __restrict__ geom, int pass, int n_tiles)
 {
     __shared__ uint32_t lds[5];
+    const int64_t L = scan_row_len(geom, blockIdx.y, pass, n_tiles, L_in);
+    if ((int64_t)blockIdx.x * kScanChunk >= L) return;
     uint32_t* row = data + (int64_t)blockIdx.y * row_stride;
     const int64_t b = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 16;
     uint32_t v[16];
@@ -487,6 +508,8 @@ __global__ __launch_bounds__(256) void k_voxel_geom(const float* __restrict__ mm
     const float leaf[3] = {leaf0, leaf1, leaf2};
     g.n = n_dev[f];
     g.overflow = 0;
+    g.passes = 0;
+    g.bpp = 8;
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
         g.inv[a] = 1.0f / leaf[a];  // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
@@ -513,6 +536,16 @@ __global__ __launch_bounds__(256) void k_voxel_geom(const float* __restrict__ mm
     }
     g.mul1 = (uint32_t)g.div_b[0];
     g.mul2 = (uint32_t)g.div_b[0] * (uint32_t)g.div_b[1];
+    if (!g.overflow) {
+        // sort plan: the linear index is < div_b.x*div_b.y*div_b.z, so only that many bits are sorted,
+        // in the fewest passes of at most kMaxRadixBits bits (a wrapped 32-bit index falls back to 4 x 8)
+        const uint64_t cells = (uint64_t)(uint32_t)g.div_b[0] * (uint64_t)(uint32_t)g.div_b[1] * (uint64_t)(uint32_t)g.div_b[2];
+        uint32_t nbits = 32;
+        if (cells <= (1ull << 32)) nbits = cells > 1 ? 64u - (uint32_t)__clzll((long long)(cells - 1)) : 1u;
+        if (nbits < 1) nbits = 1;
+        g.passes = (nbits + kMaxRadixBits - 1) / kMaxRadixBits;
+        g.bpp = (nbits + g.passes - 1) / g.passes;
+    }
     geom[f] = g;
 }
 
@@ -544,55 +577,76 @@ __global__ __launch_bounds__(kPtThreads) void k_voxel_keys(const o3dr_point* __r
 }
 
 // =================================================================================================
-// K2b — stable LSD radix sort of (voxel index, point id), 8 bits per pass.
+// K2b — stable LSD radix sort of (voxel index, point id).
 //   PCL sorts with std::sort (order inside a voxel unspecified); the canonical order here is the
-//   stable one: points of a voxel stay in ascending input order.  A workgroup owns 8192 consecutive
-//   records, a wave 1024 of them, visited in 16 rounds of 64 lanes so that (round, lane) order is
-//   input order.  Ranks come from wave ballots (match-any on the digit) plus per-wave LDS counters.
+//   stable one: points of a voxel stay in ascending input order.  Each frame sorts only the bits its
+//   index can take, in g.passes passes of g.bpp <= 10 bits (k_voxel_geom); pass p reads buffer p&1
+//   and writes the other, so a frame's sorted records end in buffer g.passes&1.  A workgroup owns
+//   8192 consecutive records, a wave 1024 of them, visited in 16 rounds of 64 lanes so that
+//   (round, lane) order is input order.  Ranks come from wave ballots (match-any on the digit) plus
+//   per-wave LDS counters: no atomics, hence stable and deterministic.
 // =================================================================================================
-__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t cap,
-                                                             const VoxelGeom* __restrict__ geom, int shift,
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __restrict__ keys0,
+                                                             const uint32_t* __restrict__ keys1, int64_t cap,
+                                                             const VoxelGeom* __restrict__ geom, int pass,
                                                              int n_tiles, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t h[kRadix];
+    __shared__ uint32_t h[kMaxRadix];
     const int f = blockIdx.y, tile = blockIdx.x;
-    const uint32_t n = geom[f].n;
-    if (geom[f].overflow) return;
-    for (int i = threadIdx.x; i < kRadix; i += kSortThreads) h[i] = 0;
+    const VoxelGeom g = geom[f];
+    if (g.overflow || pass >= (int)g.passes) return;
+    const uint32_t n = g.n;
+    const int bins = 1 << g.bpp, shift = pass * (int)g.bpp;
+    const uint32_t dmask = (uint32_t)bins - 1u;
+    for (int i = threadIdx.x; i < bins; i += kSortThreads) h[i] = 0;
     __syncthreads();
-    const uint32_t* src = keys + (int64_t)f * cap;
+    const uint32_t* src = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
     const int64_t base = (int64_t)tile * kSortTile;
+    const int lane = threadIdx.x & 63;
     if (base < n) {
 #pragma unroll 4
         for (int r = 0; r < kSortRounds; ++r) {
-            const int64_t i = base + (int64_t)(threadIdx.x >> 6) * kSortWaveItems + r * kWave + (threadIdx.x & 63);
-            if (i < n) atomicAdd(&h[(src[i] >> shift) & (kRadix - 1)], 1u);
+            const int64_t i = base + (int64_t)(threadIdx.x >> 6) * kSortWaveItems + r * kWave + lane;
+            const bool ok = i < n;
+            const uint32_t dgt = ok ? ((src[i] >> shift) & dmask) : 0u;
+            const uint64_t okb = __ballot(ok);
+            if (okb == 0) continue;
+            const int leader = __ffsll((long long)okb) - 1;
+            const uint32_t first = __shfl(dgt, leader, 64);
+            if (__ballot(ok && dgt != first) == 0) {  // whole wave in one bin (high digits): one add
+                if (lane == leader) atomicAdd(&h[first], (uint32_t)__popcll(okb));
+            } else if (ok) {
+                atomicAdd(&h[dgt], 1u);
+            }
         }
     }
     __syncthreads();
-    uint32_t* dst = hist + (int64_t)f * kRadix * n_tiles;
-    for (int dgt = threadIdx.x; dgt < kRadix; dgt += kSortThreads) dst[(int64_t)dgt * n_tiles + tile] = h[dgt];
+    uint32_t* dst = hist + (int64_t)f * kMaxRadix * n_tiles;
+    for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) dst[(int64_t)dgt * n_tiles + tile] = h[dgt];
 }
 
-__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
-                                                                const uint32_t* __restrict__ vals_in,
-                                                                uint32_t* __restrict__ keys_out,
-                                                                uint32_t* __restrict__ vals_out, int64_t cap,
-                                                                const VoxelGeom* __restrict__ geom, int shift,
-                                                                int first_pass, int n_tiles,
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
+                                                                uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
+                                                                int64_t cap, const VoxelGeom* __restrict__ geom,
+                                                                int pass, int n_tiles,
                                                                 const uint32_t* __restrict__ hist_scanned)
 {
-    __shared__ uint32_t wave_cnt[kSortWaves * kRadix];  // 8 KiB
+    __shared__ uint32_t wave_cnt[kSortWaves * kMaxRadix];  // 32 KiB
     const int f = blockIdx.y, tile = blockIdx.x;
-    const uint32_t n = geom[f].n;
-    if (geom[f].overflow) return;
+    const VoxelGeom g = geom[f];
+    if (g.overflow || pass >= (int)g.passes) return;
+    const uint32_t n = g.n;
     const int64_t base = (int64_t)tile * kSortTile;
     if (base >= n) return;
+    const int bpp = (int)g.bpp, bins = 1 << bpp, shift = pass * bpp;
+    const uint32_t dmask = (uint32_t)bins - 1u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t* kin = keys_in + (int64_t)f * cap;
-    const uint32_t* vin = vals_in + (int64_t)f * cap;
+    const uint32_t* kin = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
+    const uint32_t* vin = ((pass & 1) ? vals1 : vals0) + (int64_t)f * cap;
+    uint32_t* kout = ((pass & 1) ? keys0 : keys1) + (int64_t)f * cap;
+    uint32_t* vout = ((pass & 1) ? vals0 : vals1) + (int64_t)f * cap;
 
-    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) wave_cnt[i] = 0;
+    for (int i = threadIdx.x; i < kSortWaves * bins; i += kSortThreads) wave_cnt[(i / bins) * kMaxRadix + (i % bins)] = 0;
     __syncthreads();
 
     uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
@@ -602,22 +656,24 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         const int64_t i = wbase + r * kWave + lane;
         const bool ok = i < n;
         key[r] = ok ? kin[i] : 0xffffffffu;
-        val[r] = first_pass ? (uint32_t)i : (ok ? vin[i] : 0u);
+        val[r] = (pass == 0) ? (uint32_t)i : (ok ? vin[i] : 0u);
     }
-    volatile uint32_t* wc = wave_cnt + w * kRadix;
+    volatile uint32_t* wc = wave_cnt + w * kMaxRadix;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
         const int64_t i = wbase + r * kWave + lane;
         const bool ok = i < n;
-        const uint32_t dgt = (key[r] >> shift) & (kRadix - 1);
+        const uint32_t dgt = (key[r] >> shift) & dmask;
         // lanes of this round holding the same digit
         uint64_t peers = __ballot(ok);
 #pragma unroll
-        for (int b = 0; b < kRadixBits; ++b) {
-            const bool bit = (dgt >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+        for (int b = 0; b < kMaxRadixBits; ++b) {
+            if (b < bpp) {
+                const bool bit = (dgt >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
         }
         uint32_t prior = 0;
         if (ok) prior = wc[dgt];
@@ -628,25 +684,23 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     }
     __syncthreads();
     // exclusive offsets: global start of (digit, tile) + counts of lower waves
-    const uint32_t* hs = hist_scanned + (int64_t)f * kRadix * n_tiles;
-    for (int dgt = threadIdx.x; dgt < kRadix; dgt += kSortThreads) {
+    const uint32_t* hs = hist_scanned + (int64_t)f * kMaxRadix * n_tiles;
+    for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) {
         uint32_t run = hs[(int64_t)dgt * n_tiles + tile];
 #pragma unroll
         for (int ww = 0; ww < kSortWaves; ++ww) {
-            const uint32_t t = wave_cnt[ww * kRadix + dgt];
-            wave_cnt[ww * kRadix + dgt] = run;
+            const uint32_t t = wave_cnt[ww * kMaxRadix + dgt];
+            wave_cnt[ww * kMaxRadix + dgt] = run;
             run += t;
         }
     }
     __syncthreads();
-    uint32_t* kout = keys_out + (int64_t)f * cap;
-    uint32_t* vout = vals_out + (int64_t)f * cap;
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
         const int64_t i = wbase + r * kWave + lane;
         if (i < n) {
-            const uint32_t dgt = (key[r] >> shift) & (kRadix - 1);
-            const uint32_t dstpos = wave_cnt[w * kRadix + dgt] + rank[r];
+            const uint32_t dgt = (key[r] >> shift) & dmask;
+            const uint32_t dstpos = wave_cnt[w * kMaxRadix + dgt] + rank[r];
             kout[dstpos] = key[r];
             vout[dstpos] = val[r];
         }
@@ -658,15 +712,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
 //   third/fourth pass of VoxelGrid::applyFilter + CentroidPoint<PointXYZRGB>
 //   [PCL 1.8 common/impl/accumulators.hpp: fp32 sums, xyz / n, uint32_t(channel / n)]
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ keys, int64_t cap,
-                                                   const VoxelGeom* __restrict__ geom, int n_tiles,
+__device__ __forceinline__ const uint32_t* sorted_buf(const VoxelGeom& g, const uint32_t* b0, const uint32_t* b1)
+{
+    return (g.passes & 1u) ? b1 : b0;
+}
+
+__global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ keys1,
+                                                   int64_t cap, const VoxelGeom* __restrict__ geom, int n_tiles,
                                                    uint32_t* __restrict__ seg_cnt)
 {
     __shared__ uint32_t lds[4];
     const int f = blockIdx.y, tile = blockIdx.x;
-    if (geom[f].overflow) return;
-    const uint32_t n = geom[f].n;
-    const uint32_t* k = keys + (int64_t)f * cap;
+    const VoxelGeom g = geom[f];
+    if (g.overflow) return;
+    const uint32_t n = g.n;
+    const uint32_t* k = sorted_buf(g, keys0, keys1) + (int64_t)f * cap;
     uint32_t c = 0;
     const int64_t base = (int64_t)tile * kSegTile;
     if (base < n) {
@@ -682,19 +742,20 @@ __global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ 
     if (threadIdx.x == 0) seg_cnt[(int64_t)f * n_tiles + tile] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-__global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__ keys, int64_t cap,
-                                                    const VoxelGeom* __restrict__ geom, int n_tiles,
+__global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ keys1,
+                                                    int64_t cap, const VoxelGeom* __restrict__ geom, int n_tiles,
                                                     const uint32_t* __restrict__ seg_off,
                                                     const uint32_t* __restrict__ n_vox,
                                                     uint32_t* __restrict__ seg_start)
 {
     __shared__ uint32_t scan_lds[5];
     const int f = blockIdx.y, tile = blockIdx.x;
-    if (geom[f].overflow) return;
-    const uint32_t n = geom[f].n;
+    const VoxelGeom g = geom[f];
+    if (g.overflow) return;
+    const uint32_t n = g.n;
     const int64_t base = (int64_t)tile * kSegTile;
     if (base >= n) return;
-    const uint32_t* k = keys + (int64_t)f * cap;
+    const uint32_t* k = sorted_buf(g, keys0, keys1) + (int64_t)f * cap;
     uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
     if (tile == 0 && threadIdx.x == 0) ss[n_vox[f]] = n;  // sentinel: end of the last run
     uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
@@ -762,11 +823,12 @@ __global__ __launch_bounds__(256) void k_keep_write(const uint32_t* __restrict__
 __global__ void k_frame_offsets(const VoxelGeom* __restrict__ geom, const uint32_t* __restrict__ n_vox,
                                 const uint32_t* __restrict__ n_keep, int frames, int passthrough,
                                 uint32_t* __restrict__ n_out, uint64_t* __restrict__ out_off,
-                                CloudCounters* __restrict__ cc)
+                                CloudCounters* __restrict__ cc, SortStats* __restrict__ stats)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     uint64_t run = cc->count;
     uint32_t st = 0;
+    uint64_t rec_passes = 0, pts = 0, outs = 0;
     for (int f = 0; f < frames; ++f) {
         uint32_t m;
         if (passthrough) {
@@ -776,6 +838,9 @@ __global__ void k_frame_offsets(const VoxelGeom* __restrict__ geom, const uint32
             st |= O3DR_STATUS_VOXEL_OVERFLOW;
         } else {
             m = n_keep ? n_keep[f] : n_vox[f];
+            rec_passes += (uint64_t)geom[f].n * geom[f].passes;
+            pts += geom[f].n;
+            outs += m;
         }
         n_out[f] = m;
         out_off[f] = run;
@@ -783,10 +848,16 @@ __global__ void k_frame_offsets(const VoxelGeom* __restrict__ geom, const uint32
     }
     cc->count = run;
     cc->status |= st;
+    if (stats) {
+        stats->sort_record_passes += rec_passes;
+        stats->voxel_points_in += pts;
+        stats->voxel_points_out += outs;
+    }
 }
 
 __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __restrict__ in, int64_t in_fstride,
-                                                         const uint32_t* __restrict__ vals, int64_t cap,
+                                                         const uint32_t* __restrict__ vals0,
+                                                         const uint32_t* __restrict__ vals1, int64_t cap,
                                                          const uint32_t* __restrict__ seg_start,
                                                          const uint32_t* __restrict__ keep_idx,
                                                          const VoxelGeom* __restrict__ geom,
@@ -803,26 +874,39 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
         dst[o] = src[o];
         return;
     }
-    if (geom[f].overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
+    const VoxelGeom g = geom[f];
+    if (g.overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
         uint4 v = src[o];
         v.z = __float_as_uint((__uint_as_float(v.z) + z_offset) - z_offset);
         dst[o] = v;
         return;
     }
     const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
-    const uint32_t* pid = vals + (int64_t)f * cap;
+    const uint32_t* pid = sorted_buf(g, vals0, vals1) + (int64_t)f * cap;
     const uint32_t v = keep_idx ? keep_idx[(int64_t)f * cap + o] : (uint32_t)o;
     const uint32_t b = ss[v], e = ss[v + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
-    for (uint32_t li = b; li < e; ++li) {
-        const uint4 p = src[pid[li]];
-        sx += __uint_as_float(p.x);
-        sy += __uint_as_float(p.y);
-        sz += __uint_as_float(p.z) + z_offset;
-        sr += (float)((p.w >> 16) & 255u);
-        sg += (float)((p.w >> 8) & 255u);
-        sb += (float)(p.w & 255u);
-        sa += (float)(p.w >> 24);
+    // the sums are strictly sequential (input order); the loads are not: 8 gathers in flight
+    for (uint32_t li = b; li < e; li += 8) {
+        uint32_t id[8];
+        uint4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) id[k] = (li + k < e) ? pid[li + k] : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (id[k] != 0xffffffffu) p[k] = src[id[k]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (id[k] != 0xffffffffu) {
+                sx += __uint_as_float(p[k].x);
+                sy += __uint_as_float(p[k].y);
+                sz += __uint_as_float(p[k].z) + z_offset;
+                sr += (float)((p[k].w >> 16) & 255u);
+                sg += (float)((p[k].w >> 8) & 255u);
+                sb += (float)(p[k].w & 255u);
+                sa += (float)(p[k].w >> 24);
+            }
+        }
     }
     const float nf = (float)(e - b);
     const float cx = sx / nf, cy = sy / nf, cz = sz / nf - z_offset;
@@ -836,18 +920,20 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
 // =================================================================================================
 static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// exclusive scan of `frames` rows of length L in place; totals[f] = row sum (+ add[f])
+// exclusive scan of `frames` rows of length L in place; totals[f] = row sum (+ add[f]).
+// With geom != nullptr the rows are radix histograms of pass `pass` (live length per frame).
 static void launch_scan(hipStream_t s, uint32_t* data, int64_t L, int64_t row_stride, int frames, uint32_t* totals,
-                        const uint32_t* add, uint32_t* partial)
+                        const uint32_t* add, uint32_t* partial, const VoxelGeom* geom = nullptr, int pass = 0,
+                        int n_tiles = 0)
 {
     if (L <= 2 * kScanChunk) {
-        k_scan_rows<<<frames, 1024, 0, s>>>(data, L, row_stride, totals, add);
+        k_scan_rows<<<frames, 1024, 0, s>>>(data, L, row_stride, totals, add, geom, pass, n_tiles, 0);
         return;
     }
     const int n_chunks = cdiv64(L, kScanChunk);
-    k_scan_chunk_sums<<<dim3(n_chunks, frames), 256, 0, s>>>(data, L, row_stride, n_chunks, partial);
-    k_scan_rows<<<frames, 1024, 0, s>>>(partial, n_chunks, n_chunks, totals, add);
-    k_scan_chunk_apply<<<dim3(n_chunks, frames), 256, 0, s>>>(data, L, row_stride, n_chunks, partial);
+    k_scan_chunk_sums<<<dim3(n_chunks, frames), 256, 0, s>>>(data, L, row_stride, n_chunks, partial, geom, pass, n_tiles);
+    k_scan_rows<<<frames, 1024, 0, s>>>(partial, L, n_chunks, totals, add, geom, pass, n_tiles, 1);
+    k_scan_chunk_apply<<<dim3(n_chunks, frames), 256, 0, s>>>(data, L, row_stride, n_chunks, partial, geom, pass, n_tiles);
 }
 
 void launch_minmax_init(Profiler* pf, hipStream_t s, float* mm, int64_t mm_stride, int slot, uint32_t* n_kp, int frames)
@@ -934,32 +1020,30 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, ws.geom,
                                                                                     v.z_offset, cap, ws.keys[0]);
         }
-        int cur = 0;
-        for (int pass = 0; pass < 32 / kRadixBits; ++pass) {
-            const int shift = pass * kRadixBits;
+        // always 4 launches; frames whose index needs fewer passes drop out on the device
+        const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
+        for (int pass = 0; pass < kMaxPasses; ++pass) {
             const dim3 grid(n_sort_tiles, F);
             {
                 ProfScope ps(pf, O3DR_K_SORT_HIST, s);
-                k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[cur], cap, ws.geom, shift, n_sort_tiles, ws.hist);
+                k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles,
+                                                          ws.hist);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
-                launch_scan(s, ws.hist, (int64_t)kRadix * n_sort_tiles, (int64_t)kRadix * n_sort_tiles, F, nullptr, nullptr,
-                            ws.scan_partial);
+                launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, ws.geom, pass,
+                            n_sort_tiles);
             }
             {
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
-                k_radix_scatter<<<grid, kSortThreads, 0, s>>>(ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1],
-                                                             ws.vals[cur ^ 1], cap, ws.geom, shift, pass == 0,
-                                                             n_sort_tiles, ws.hist);
+                k_radix_scatter<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                             ws.geom, pass, n_sort_tiles, ws.hist);
             }
-            cur ^= 1;
         }
-        // cur == 0 again after 4 passes
         const dim3 sgrid(n_seg_tiles, F);
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[cur], cap, ws.geom, n_seg_tiles, ws.seg_cnt);
+            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt);
         }
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -967,7 +1051,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         }
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[cur], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
+            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
                                               ws.seg_start);
         }
         if (v.min_points > 1) {
@@ -990,13 +1074,15 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     }
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
-        k_frame_offsets<<<1, 1, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc);
+        k_frame_offsets<<<1, 1, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc,
+                                        v.stats);
     }
     if (cap > 0) {
         ProfScope ps(pf, O3DR_K_CENTROID, s);
         k_centroid<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
-            v.in, v.in_fstride, ws.vals[0], cap, ws.seg_start, (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr,
-            ws.geom, ws.n_out, ws.out_off, v.z_offset, v.passthrough, v.out_base);
+            v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start,
+            (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, ws.geom, ws.n_out, ws.out_off, v.z_offset,
+            v.passthrough, v.out_base);
     }
 }
 
