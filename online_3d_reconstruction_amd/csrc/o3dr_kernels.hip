@@ -631,13 +631,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
                                                                 int pass, int n_tiles,
                                                                 const uint32_t* __restrict__ hist_scanned)
 {
-    __shared__ uint32_t wave_cnt[kSortWaves * kMaxRadix];  // 32 KiB
+    __shared__ uint32_t wave_cnt[kSortWaves * kMaxRadix];  // per-wave digit counts -> exclusive wave prefixes
+    __shared__ uint32_t local_base[kMaxRadix];             // start of each digit inside the tile's sorted order
+    __shared__ uint32_t delta[kMaxRadix];                  // global start of (digit, tile) - local_base
+    __shared__ uint32_t stage[kSortTile];                  // the tile's keys, then ids, in sorted order
+    __shared__ uint32_t scan_lds[kSortWaves + 1];
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom[f];
     if (g.overflow || pass >= (int)g.passes) return;
     const uint32_t n = g.n;
     const int64_t base = (int64_t)tile * kSortTile;
     if (base >= n) return;
+    const uint32_t cnt = (n - base < (uint32_t)kSortTile) ? (uint32_t)(n - base) : (uint32_t)kSortTile;
     const int bpp = (int)g.bpp, bins = 1 << bpp, shift = pass * bpp;
     const uint32_t dmask = (uint32_t)bins - 1u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -646,9 +651,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
     uint32_t* kout = ((pass & 1) ? keys0 : keys1) + (int64_t)f * cap;
     uint32_t* vout = ((pass & 1) ? vals0 : vals1) + (int64_t)f * cap;
 
-    for (int i = threadIdx.x; i < kSortWaves * bins; i += kSortThreads) wave_cnt[(i / bins) * kMaxRadix + (i % bins)] = 0;
+    for (int i = threadIdx.x; i < kSortWaves * kMaxRadix; i += kSortThreads) wave_cnt[i] = 0;
     __syncthreads();
 
+    // ---- 1. load 16 records per lane; rank every record among the wave's earlier same-digit records
     uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
     const int64_t wbase = base + (int64_t)w * kSortWaveItems;
 #pragma unroll
@@ -665,8 +671,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
         const int64_t i = wbase + r * kWave + lane;
         const bool ok = i < n;
         const uint32_t dgt = (key[r] >> shift) & dmask;
-        // lanes of this round holding the same digit
-        uint64_t peers = __ballot(ok);
+        uint64_t peers = __ballot(ok);  // lanes of this round holding the same digit
 #pragma unroll
         for (int b = 0; b < kMaxRadixBits; ++b) {
             if (b < bpp) {
@@ -683,27 +688,68 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // exclusive offsets: global start of (digit, tile) + counts of lower waves
-    const uint32_t* hs = hist_scanned + (int64_t)f * kMaxRadix * n_tiles;
-    for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) {
-        uint32_t run = hs[(int64_t)dgt * n_tiles + tile];
+
+    // ---- 2. two adjacent digits per thread: wave prefixes, tile totals, local starts, global deltas
+    uint32_t tot[2] = {0, 0};
 #pragma unroll
-        for (int ww = 0; ww < kSortWaves; ++ww) {
-            const uint32_t t = wave_cnt[ww * kMaxRadix + dgt];
-            wave_cnt[ww * kMaxRadix + dgt] = run;
-            run += t;
+    for (int j = 0; j < 2; ++j) {
+        const int dg = 2 * threadIdx.x + j;
+        if (dg < bins) {
+#pragma unroll
+            for (int ww = 0; ww < kSortWaves; ++ww) {
+                const uint32_t t = wave_cnt[ww * kMaxRadix + dg];
+                wave_cnt[ww * kMaxRadix + dg] = tot[j];
+                tot[j] += t;
+            }
         }
     }
+    uint32_t tile_total;
+    uint32_t lb = block_excl_scan_u32<kSortWaves>(tot[0] + tot[1], scan_lds, tile_total);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int dg = 2 * threadIdx.x + j;
+        if (dg < bins) {
+            local_base[dg] = lb;
+            delta[dg] = hist_scanned[(int64_t)f * kMaxRadix * n_tiles + (int64_t)dg * n_tiles + tile] - lb;
+        }
+        lb += tot[j];
+    }
     __syncthreads();
+
+    // ---- 3. keys: into LDS at their sorted position, out to HBM in runs of equal digit (coalesced)
+    uint32_t pos[kSortRounds];
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
         const int64_t i = wbase + r * kWave + lane;
         if (i < n) {
             const uint32_t dgt = (key[r] >> shift) & dmask;
-            const uint32_t dstpos = wave_cnt[w * kMaxRadix + dgt] + rank[r];
-            kout[dstpos] = key[r];
-            vout[dstpos] = val[r];
+            pos[r] = local_base[dgt] + wave_cnt[w * kMaxRadix + dgt] + rank[r];
+            stage[pos[r]] = key[r];
         }
+    }
+    __syncthreads();
+    uint32_t dst[kSortRounds];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t p = r * kSortThreads + threadIdx.x;
+        if (p < cnt) {
+            const uint32_t k = stage[p];
+            dst[r] = p + delta[(k >> shift) & dmask];
+            kout[dst[r]] = k;
+        }
+    }
+    __syncthreads();
+    // ---- 4. ids the same way, reusing the positions
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = wbase + r * kWave + lane;
+        if (i < n) stage[pos[r]] = val[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t p = r * kSortThreads + threadIdx.x;
+        if (p < cnt) vout[dst[r]] = stage[p];
     }
 }
 
