@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; collected separately, kernel-trace only)
+into profiles/<tag>_pmc_traffic.json: HBM bytes per launch for every kernel, with the gfx950
+corrections of MI355X_MICROARCH.md "HBM": FETCH_SIZE reports half of the bytes of coalesced
+streaming reads (verified here: k_voxel_keys reads exactly 16 B/point and FETCH_SIZE*1024 is 0.500
+of that; k_radix_hist reads 4 B/record, ratio 0.500), WRITE_SIZE is exact for streaming stores
+(k_reproject_emit: 16 B/point, ratio 1.00).  Counter unit is KiB.
+
+    python profiles/make_pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, counter):
+    out = collections.defaultdict(list)
+    for path in glob.glob(f"{d}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                out[r["Kernel_Name"].split("(")[0].replace("o3dr::k_", "")].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch_dir, write_dir, out_path = sys.argv[1:4]
+    dominant = sys.argv[4] if len(sys.argv) > 4 else "radix_scatter"
+    f, w = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(f) | set(w)):
+        n = max(len(f.get(k, [])), len(w.get(k, [])), 1)
+        fetch = 2.0 * sum(f.get(k, [])) * 1024.0  # x2: gfx950 FETCH_SIZE counts 64 B per 128-B request
+        write = sum(w.get(k, [])) * 1024.0
+        kernels[k] = {"launches": n, "fetch_bytes_per_launch": round(fetch / n), "write_bytes_per_launch": round(write / n),
+                      "hbm_bytes_per_launch": round((fetch + write) / n)}
+    doc = {"kernel": dominant, "hbm_bytes_per_launch": kernels.get(dominant, {}).get("hbm_bytes_per_launch"),
+           "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes", "kernels": kernels}
+    json.dump(doc, open(out_path, "w"), indent=1)
+    print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in kernels.items()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,13 @@ def main():
     header, v, tail = read_ply_vertices(f"{REF}/cloud.ply")
     np.savez_compressed(f"{OUT}/cloud_ply.npz", header=np.frombuffer(header.encode(), np.uint8),
                         vertices=v, tail=np.frombuffer(tail, np.uint8))
+    # pose / image-time tables (data): the timestamp -> pose binding of the CLI depends on the whole
+    # table (binary-search path), so they are kept whole, gzip-compressed
+    import gzip
+    for name in ("pose.txt", "images.txt"):
+        raw = open(f"{REF}/data_files/{name}", "rb").read()
+        with gzip.GzipFile(f"{OUT}/{name}.gz", "wb", mtime=0) as g:
+            g.write(raw)
     print("Q =", Q.ravel())
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(f"{OUT}/{f}"))
