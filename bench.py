@@ -3,8 +3,8 @@
 
 One "step" = one pass of the whole hot path over this rank's shard of synthetic frames, inputs
 already resident in HBM:  cloud_big reset -> A6 for every frame (fused reproject + SE(3), per-frame
-voxel grid), appended in frame order -> [N>1: exchange of the per-frame voxel clouds over RCCL] ->
-combined 2.5-D merge (pose.cpp:530).  Workload = BASELINE.json configs[1]: synthetic 1280x720 dense
+voxel grid), appended in frame order -> [N>1: index-slice partition + one RCCL all-to-all of the
+per-frame voxel clouds] -> combined 2.5-D merge (pose.cpp:530) [N>1: all-gather of the merged slices].  Workload = BASELINE.json configs[1]: synthetic 1280x720 dense
 (jump_pixels 1), 200 frames per GPU, voxel_size 0.05.
 
     python bench.py                       # N=1, defaults finish in a few minutes
@@ -137,10 +137,11 @@ def main():
         ctx.cloudBigReset()
         ctx.accumulateFrames(disp, bgr, poses)
         if world > 1:
-            m1 = o3dist.exchange_cloud_big(ctx, dev)
+            # index-slice partition + one all-to-all + local merge + all-gather of the merged slices
+            out, m1 = o3dist.merge_partitioned(ctx, dev)
         else:
             m1, _ = ctx.cloudBigSize()
-        out = ctx.finalize(device=dev)
+            out = ctx.finalize(device=dev)
         state["m1_total"] = m1
         state["m2"] = int(out.shape[0])
         return out
@@ -187,7 +188,7 @@ def main():
     # ---- algorithmic bytes per step (DESIGN.md "Kernels and rooflines") --------------------------------
     rec_passes, vox_in, vox_out = (v / args.steps for v in stats)  # device counters over the timed region
     nv = n_valid_total  # valid points of this rank's frames (per step)
-    merge_n = m1_total  # points entering the combined merge on this rank
+    merge_n = m1_total // world  # points entering the combined merge on this rank (its index slice)
     bytes_per_step = {
         "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate
         "reproject_emit": 4 * n_cand * F + 16 * nv,            # 1 B disparity + 3 B colour in, 16 B point out

@@ -187,6 +187,23 @@ int o3dr_cloud_big_transform(o3dr_ctx* ctx, const float T[16]);
 int o3dr_finalize(o3dr_ctx* ctx, o3dr_point* out, int64_t out_capacity, int64_t* n_out,
                   uint32_t* status, int32_t mem);
 
+/* ---- multi-GPU merge (frames sharded over ranks) ------------------------------
+ * The reference's final merge (pose.cpp:530) runs one voxel grid over ALL frames' per-frame voxels.
+ * With one rank per GPU: (1) every rank takes o3dr_cloud_big_bbox and the ranks min/max-reduce it;
+ * (2) o3dr_cloud_big_partition lays the combined grid (params: voxel_size, +500 z offset) over that
+ * GLOBAL box, cuts its linear index range into n_parts equal slices and stably reorders cloud_big so
+ * that slice 0's points come first: counts[p] = points of slice p; (3) the ranks exchange slices
+ * (all-to-all over RCCL; received segments appended in source-rank order keep global order);
+ * (4) o3dr_finalize_global merges the local slice with the grid over the same global box.  The
+ * concatenation of the ranks' outputs in rank order equals the single-GPU result bit for bit.
+ * When PCL's overflow guard fires for the global box, *status carries O3DR_STATUS_VOXEL_OVERFLOW, the
+ * cloud is left as is and all counts are 0 (the merge then returns its input: skip the exchange). */
+int o3dr_cloud_big_bbox(o3dr_ctx* ctx, float mn[3], float mx[3], int64_t* n);
+int o3dr_cloud_big_partition(o3dr_ctx* ctx, const float gmin[3], const float gmax[3], int32_t n_parts,
+                             int64_t* counts, uint32_t* status);
+int o3dr_finalize_global(o3dr_ctx* ctx, const float gmin[3], const float gmax[3], o3dr_point* out,
+                         int64_t out_capacity, int64_t* n_out, uint32_t* status, int32_t mem);
+
 /* ---- measurement hooks (bench.py; not part of the reference surface) ------------------------ */
 /* kernel ids for o3dr_profile_* */
 #define O3DR_K_COUNT        0  /* grid-pass valid count per tile */

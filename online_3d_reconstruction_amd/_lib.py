@@ -63,6 +63,9 @@ SYMBOLS = [
     ("o3dr_cloud_big_append", C.c_int, [_vp, _vp, _i64, _i32]),
     ("o3dr_cloud_big_transform", C.c_int, [_vp, _vp]),
     ("o3dr_finalize", C.c_int, [_vp, _vp, _i64, _pi64, _pu32, _i32]),
+    ("o3dr_cloud_big_bbox", C.c_int, [_vp, _vp, _vp, _pi64]),
+    ("o3dr_cloud_big_partition", C.c_int, [_vp, _vp, _vp, _i32, _pi64, _pu32]),
+    ("o3dr_finalize_global", C.c_int, [_vp, _vp, _vp, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_profile_enable", C.c_int, [_vp, _i32, _i32]),
     ("o3dr_profile_read", C.c_int, [_vp, _i32, C.POINTER(C.c_double), _pi64]),
     ("o3dr_profile_reset", C.c_int, [_vp]),

@@ -271,8 +271,26 @@ class Context:
         Tn = self._T(T)
         L.check(self._lib.o3dr_cloud_big_transform(self._h, Tn.ctypes.data))
 
-    def finalize(self, device=None, return_status=False):
-        """cloud_small = downsamplePtCloud(cloud_big, true) (pose.cpp:530)."""
+    def cloudBigBBox(self):
+        """(min xyz, max xyz, count) of cloud_big; (+inf, -inf, 0) when empty"""
+        mn = np.empty(3, np.float32)
+        mx = np.empty(3, np.float32)
+        n = C.c_int64(0)
+        L.check(self._lib.o3dr_cloud_big_bbox(self._h, mn.ctypes.data, mx.ctypes.data, C.byref(n)))
+        return mn, mx, n.value
+
+    def cloudBigPartition(self, gmin, gmax, n_parts):
+        """stable reorder of cloud_big by index slice of the combined grid over [gmin, gmax]; -> (counts, status)"""
+        gmin = np.ascontiguousarray(gmin, np.float32)
+        gmax = np.ascontiguousarray(gmax, np.float32)
+        counts = (C.c_int64 * n_parts)()
+        st = C.c_uint32(0)
+        L.check(self._lib.o3dr_cloud_big_partition(self._h, gmin.ctypes.data, gmax.ctypes.data, n_parts, counts, C.byref(st)))
+        return [int(v) for v in counts], st.value
+
+    def finalize(self, device=None, return_status=False, gmin=None, gmax=None):
+        """cloud_small = downsamplePtCloud(cloud_big, true) (pose.cpp:530); with gmin/gmax the grid is laid
+        over that (global) bounding box instead of cloud_big's own (multi-GPU merge)."""
         n, _ = self.cloudBigSize()
         if device is not None:
             import torch
@@ -282,7 +300,13 @@ class Context:
         po, mem, _k = _ptr(out)
         m = C.c_int64(0)
         st = C.c_uint32(0)
-        L.check(self._lib.o3dr_finalize(self._h, po, max(n, 1), C.byref(m), C.byref(st), mem))
+        if gmin is None:
+            L.check(self._lib.o3dr_finalize(self._h, po, max(n, 1), C.byref(m), C.byref(st), mem))
+        else:
+            gmin = np.ascontiguousarray(gmin, np.float32)
+            gmax = np.ascontiguousarray(gmax, np.float32)
+            L.check(self._lib.o3dr_finalize_global(self._h, gmin.ctypes.data, gmax.ctypes.data, po, max(n, 1), C.byref(m),
+                                                  C.byref(st), mem))
         return (out[: m.value], st.value) if return_status else out[: m.value]
 
     # -- measurement hooks --------------------------------------------------------------------------

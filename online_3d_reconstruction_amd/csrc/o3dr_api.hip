@@ -71,6 +71,8 @@ struct o3dr_ctx {
     CloudCounters* cc_tmp = nullptr;   // device, for single-shot calls
     CloudCounters* cc_host = nullptr;  // pinned
     uint32_t* n_host = nullptr;        // pinned scratch (4 words)
+    uint8_t* misc_dev = nullptr;       // 4 KiB device scratch: bbox (6 f32) | overflow (u32) | part counts (256 u64)
+    uint8_t* misc_host = nullptr;      // pinned mirror
     SortStats* stats_dev = nullptr;    // device statistics (bench.py byte accounting)
     SortStats* stats_host = nullptr;   // pinned
 
@@ -228,6 +230,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
         hipHostMalloc((void**)&c->cc_host, sizeof(CloudCounters), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->n_host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->stats_dev, sizeof(SortStats)) != hipSuccess ||
+        hipMalloc((void**)&c->misc_dev, 4096) != hipSuccess ||
+        hipHostMalloc((void**)&c->misc_host, 4096, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->stats_host, sizeof(SortStats), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(O3DR_ERR_ALLOC, "counter allocation failed");
@@ -260,6 +264,8 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->cc_host) (void)hipHostFree(c->cc_host);
     if (c->n_host) (void)hipHostFree(c->n_host);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
+    if (c->misc_dev) (void)hipFree(c->misc_dev);
+    if (c->misc_host) (void)hipHostFree(c->misc_host);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -567,12 +573,26 @@ extern "C" int o3dr_transform_pt_cloud(o3dr_ctx* c, const o3dr_point* in, int64_
 }
 
 // one stand-alone voxel grid over a device cloud -> device destination; returns count + status
+// write a host-supplied bounding box (min xyz, max xyz) into bounding-box slot 0 of frame 0
+static int put_bbox(o3dr_ctx* c, const float mn[3], const float mx[3])
+{
+    float* h = (float*)c->misc_host;
+    for (int a = 0; a < 3; ++a) h[a] = mn[a], h[3 + a] = mx[a];
+    HIPCHK(hipMemcpyAsync(c->ws.mm, h, 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return O3DR_OK;
+}
+
 static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const float leaf[3], uint32_t min_points,
-                        float z_offset, o3dr_point* out_d, int64_t* n_out, uint32_t* status)
+                        float z_offset, o3dr_point* out_d, int64_t* n_out, uint32_t* status,
+                        const float* gmin = nullptr, const float* gmax = nullptr)
 {
     CHK(ws_ensure(c, 1, n_in, false));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
-    const int mm_used = launch_points_minmax(&c->prof, c->stream, in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
+    int mm_used = 1;
+    if (gmin && gmax)  // grid laid over a caller-supplied (global) box instead of this cloud's own
+        CHK(put_bbox(c, gmin, gmax));
+    else
+        mm_used = launch_points_minmax(&c->prof, c->stream, in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
     CHK(zero_counters(c, c->cc_tmp));
     VoxelArgs v;
     v.in = in_d;
@@ -852,8 +872,8 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
     return O3DR_OK;
 }
 
-extern "C" int o3dr_finalize(o3dr_ctx* c, o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
-                             int32_t mem)
+static int finalize_impl(o3dr_ctx* c, const float* gmin, const float* gmax, o3dr_point* out, int64_t out_capacity,
+                         int64_t* n_out, uint32_t* status, int32_t mem)
 {
     if (n_out) *n_out = 0;
     if (status) *status = 0;
@@ -883,7 +903,7 @@ extern "C" int o3dr_finalize(o3dr_ctx* c, o3dr_point* out, int64_t out_capacity,
     }
     int64_t m = 0;
     uint32_t st = 0;
-    CHK(voxel_single(c, c->cloud_big, n, leaf, mp, zo, out_d, &m, &st));
+    CHK(voxel_single(c, c->cloud_big, n, leaf, mp, zo, out_d, &m, &st, gmin, gmax));
     if (mem == O3DR_MEM_HOST) {
         if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
         if (m > 0) {
@@ -893,6 +913,99 @@ extern "C" int o3dr_finalize(o3dr_ctx* c, o3dr_point* out, int64_t out_capacity,
     }
     *n_out = m;
     if (status) *status = st | cc.status;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_finalize(o3dr_ctx* c, o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
+                             int32_t mem)
+{
+    return finalize_impl(c, nullptr, nullptr, out, out_capacity, n_out, status, mem);
+}
+
+// ---- multi-GPU merge: global box -> index-slice partition -> exchange -> local merge ----
+extern "C" int o3dr_finalize_global(o3dr_ctx* c, const float gmin[3], const float gmax[3], o3dr_point* out,
+                                    int64_t out_capacity, int64_t* n_out, uint32_t* status, int32_t mem)
+{
+    if (!gmin || !gmax) {
+        if (n_out) *n_out = 0;
+        return fail(O3DR_ERR_INVALID_ARG, "bounding box is NULL");
+    }
+    return finalize_impl(c, gmin, gmax, out, out_capacity, n_out, status, mem);
+}
+
+extern "C" int o3dr_cloud_big_bbox(o3dr_ctx* c, float mn[3], float mx[3], int64_t* n_out)
+{
+    CTX_ENTER(c);
+    if (!mn || !mx) return fail(O3DR_ERR_INVALID_ARG, "bounding box is NULL");
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_big, &cc));
+    const int64_t n = (int64_t)cc.count;
+    c->cloud_ub = n;
+    if (n_out) *n_out = n;
+    for (int a = 0; a < 3; ++a) mn[a] = __builtin_inff(), mx[a] = -__builtin_inff();
+    if (n == 0) return O3DR_OK;
+    if (n >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+    CHK(ws_ensure(c, 1, n, false));
+    launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n, 1);
+    const int used = launch_points_minmax(&c->prof, c->stream, c->cloud_big, 0, c->ws.n_valid, 1, n, c->ws.mm_stride, c->ws.mm);
+    launch_bbox(&c->prof, c->stream, c->ws.mm, used, (float*)c->misc_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->misc_host, c->misc_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const float* h = (const float*)c->misc_host;
+    for (int a = 0; a < 3; ++a) mn[a] = h[a], mx[a] = h[3 + a];
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_partition(o3dr_ctx* c, const float gmin[3], const float gmax[3], int32_t n_parts,
+                                        int64_t* counts, uint32_t* status)
+{
+    if (status) *status = 0;
+    CTX_ENTER(c);
+    if (!gmin || !gmax || !counts || n_parts < 1 || n_parts > 256) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    for (int p = 0; p < n_parts; ++p) counts[p] = 0;
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_big, &cc));
+    const int64_t n = (int64_t)cc.count;
+    c->cloud_ub = n;
+    if (n == 0) return O3DR_OK;
+    if (n >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+    CHK(ws_ensure(c, 1, n, false));
+    o3dr_point* nb = nullptr;
+    if (hipMalloc((void**)&nb, (size_t)c->cloud_cap * sizeof(o3dr_point)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(O3DR_ERR_ALLOC, "hipMalloc failed (partition buffer)");
+    }
+    launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n, 1);
+    CHK(put_bbox(c, gmin, gmax));
+    float leaf[3], zo;
+    uint32_t mp;
+    downsample_leaf(c->params, 1, leaf, &mp, &zo);
+    VoxelArgs v;
+    memset(&v, 0, sizeof v);
+    v.in = c->cloud_big;
+    v.n_dev = c->ws.n_valid;
+    v.frames = 1;
+    v.cap = n;
+    v.leaf[0] = leaf[0];
+    v.leaf[1] = leaf[1];
+    v.leaf[2] = leaf[2];
+    v.z_offset = zo;
+    uint32_t* ovf_dev = (uint32_t*)(c->misc_dev + 32);
+    uint64_t* cnt_dev = (uint64_t*)(c->misc_dev + 64);
+    launch_partition(&c->prof, c->stream, c->ws, v, n_parts, nb, cnt_dev, ovf_dev);
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFree(nb);
+        return fail(O3DR_ERR_HIP, "partition launch failed");
+    }
+    HIPCHK(hipMemcpyAsync(c->misc_host, c->misc_dev, 64 + 8 * (size_t)n_parts, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(c->cloud_big));
+    c->cloud_big = nb;
+    const uint32_t ovf = *(const uint32_t*)(c->misc_host + 32);
+    const uint64_t* hc = (const uint64_t*)(c->misc_host + 64);
+    for (int p = 0; p < n_parts; ++p) counts[p] = (int64_t)hc[p];
+    if (status) *status = ovf ? O3DR_STATUS_VOXEL_OVERFLOW : 0u;
     return O3DR_OK;
 }
 

@@ -132,5 +132,8 @@ struct VoxelArgs {
 };
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);
+void launch_bbox(Profiler* pf, hipStream_t s, const float* mm, int used, float* out6);
+void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
+                      uint64_t* counts_dev, uint32_t* overflow_dev);
 
 }  // namespace o3dr

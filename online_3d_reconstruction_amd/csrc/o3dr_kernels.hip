@@ -962,6 +962,93 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
 }
 
 // =================================================================================================
+// Multi-GPU merge support: the combined voxel grid is laid over the GLOBAL
+// bounding box of all ranks' clouds; its linear index range is cut into n_parts contiguous slices
+// and every point goes to the rank owning its slice.  Stable, so a slice's points stay in global
+// (rank, frame, index) order and the merged cells are bit-identical to a single-GPU run.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_bbox_fold(const float* __restrict__ mm, int used, float* __restrict__ out6)
+{
+    __shared__ float red[6 * 4];
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int sidx = threadIdx.x; sidx < used; sidx += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], mm[sidx * 6 + a]);
+            hi[a] = fmaxf(hi[a], mm[sidx * 6 + 3 + a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_min_f32(lo[a]), h = wave_max_f32(hi[a]);
+        if ((threadIdx.x & 63) == 0) {
+            red[(threadIdx.x >> 6) * 6 + a] = l;
+            red[(threadIdx.x >> 6) * 6 + 3 + a] = h;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        out6[a] = fminf(fminf(red[a], red[6 + a]), fminf(red[12 + a], red[18 + a]));
+        out6[3 + a] = fmaxf(fmaxf(red[3 + a], red[9 + a]), fmaxf(red[15 + a], red[21 + a]));
+    }
+}
+
+// linear voxel index -> owning part: slice p covers indices [p*cells/n_parts, (p+1)*cells/n_parts)
+__global__ __launch_bounds__(256) void k_part_ids(uint32_t* __restrict__ keys, const VoxelGeom* __restrict__ geom,
+                                                  int n_parts)
+{
+    const VoxelGeom g = geom[0];
+    if (g.overflow) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const uint64_t cells = (uint64_t)(uint32_t)g.div_b[0] * (uint64_t)(uint32_t)g.div_b[1] * (uint64_t)(uint32_t)g.div_b[2];
+    uint64_t part = (uint64_t)keys[i] * (uint64_t)n_parts / cells;
+    if (part >= (uint64_t)n_parts) part = n_parts - 1;
+    keys[i] = (uint32_t)part;
+}
+__global__ void k_part_plan(VoxelGeom* geom, int n_parts)
+{
+    if (geom[0].overflow) return;
+    uint32_t bits = 1;
+    while ((1u << bits) < (uint32_t)n_parts) ++bits;
+    geom[0].passes = 1;
+    geom[0].bpp = bits;
+}
+__global__ __launch_bounds__(256) void k_gather_points(const o3dr_point* __restrict__ in, const uint32_t* __restrict__ ids,
+                                                       const VoxelGeom* __restrict__ geom, o3dr_point* __restrict__ out)
+{
+    const VoxelGeom g = geom[0];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const uint4* src = reinterpret_cast<const uint4*>(in);
+    reinterpret_cast<uint4*>(out)[i] = g.overflow ? src[i] : src[ids[i]];
+}
+// counts[p] = records of part p in the sorted part-id array (binary search per part)
+__global__ void k_part_counts(const uint32_t* __restrict__ sorted_parts, const VoxelGeom* __restrict__ geom, int n_parts,
+                              uint64_t* __restrict__ counts, uint32_t* __restrict__ overflow)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const VoxelGeom g = geom[0];
+    if (p == 0) *overflow = g.overflow;
+    if (p >= n_parts) return;
+    if (g.overflow) {
+        counts[p] = 0;
+        return;
+    }
+    auto lower = [&](uint32_t v) {
+        uint32_t lo = 0, hi = g.n;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (sorted_parts[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    counts[p] = (uint64_t)(lower((uint32_t)p + 1) - lower((uint32_t)p));
+}
+
+// =================================================================================================
 // launchers
 // =================================================================================================
 static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -1130,6 +1217,34 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, ws.geom, ws.n_out, ws.out_off, v.z_offset,
             v.passthrough, v.out_base);
     }
+}
+
+void launch_bbox(Profiler* pf, hipStream_t s, const float* mm, int used, float* out6)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_bbox_fold<<<1, 256, 0, s>>>(mm, used, out6);
+}
+
+// Stable partition of `in` (n points, count also in v.n_dev[0]) by index slice of the voxel grid whose
+// bounding box sits in ws.mm slot 0.  out = reordered points, counts_dev[n_parts], overflow_dev = 1 when
+// PCL's overflow guard fires for that box (then out = in and every count is 0).
+void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
+                      uint64_t* counts_dev, uint32_t* overflow_dev)
+{
+    const int64_t cap = v.cap;
+    const int n_sort_tiles = cdiv64(cap, kSortTile);
+    const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_voxel_geom<<<1, 256, 0, s>>>(ws.mm, ws.mm_stride, 1, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset, ws.geom);
+    k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), 1), kPtThreads, 0, s>>>(v.in, 0, ws.geom, v.z_offset, cap, ws.keys[0]);
+    k_part_ids<<<cdiv64(cap, 256), 256, 0, s>>>(ws.keys[0], ws.geom, n_parts);
+    k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
+    k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, 0, n_sort_tiles, ws.hist);
+    launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, 0, n_sort_tiles);
+    k_radix_scatter<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, 0,
+                                                                  n_sort_tiles, ws.hist);
+    k_gather_points<<<cdiv64(cap, 256), 256, 0, s>>>(v.in, ws.vals[1], ws.geom, out);
+    k_part_counts<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.keys[1], ws.geom, n_parts, counts_dev, overflow_dev);
 }
 
 }  // namespace o3dr

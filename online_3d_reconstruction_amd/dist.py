@@ -46,3 +46,58 @@ def exchange_cloud_big(ctx, device, group=None):
         if s.shape[0]:
             ctx.cloudBigAppend(s)
     return sum(counts)
+
+
+def _all_to_all_points(send, send_counts, group=None):
+    """send: [n,4] int32, grouped by destination rank (send_counts[r] points for rank r).
+    Returns the received points, segments in source-rank order, and the receive counts."""
+    world = dist.get_world_size(group)
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+    rc = torch.empty(world, dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(v) for v in rc.tolist()]
+    recv = torch.empty((sum(recv_counts), 4), dtype=torch.int32, device=send.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=group)
+    return recv, recv_counts
+
+
+def merge_partitioned(ctx, device, group=None, gather_result=True):
+    """The reference's final merge (pose.cpp:530) over frames sharded across ranks, without replicating it:
+
+      1. all-reduce (min/max) of the ranks' cloud_big bounding boxes -> the box PCL would see;
+      2. every rank stably reorders its cloud by index slice of the combined grid over that box
+         (slice r = the r-th of `world` equal ranges of the linear voxel index);
+      3. one all-to-all (RCCL over xGMI: every peer pair uses its own link) moves slice r to rank r;
+         segments arrive in source-rank order = global frame order;
+      4. every rank merges its slice with the grid over the global box;
+      5. all-gather of the (small) merged slices; rank order = ascending voxel index.
+
+    Returns (merged [M,4] int32 tensor or this rank's slice if gather_result is False, total points merged).
+    Bit-identical to a single-GPU run over all frames."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mn, mx, n_local = ctx.cloudBigBBox()
+    box = torch.tensor(np.concatenate([mn, -mx]), dtype=torch.float32, device=device)
+    dist.all_reduce(box, op=dist.ReduceOp.MIN, group=group)  # min of mins, min of (-max) = -(max of maxes)
+    box = box.cpu().numpy()
+    gmin, gmax = box[:3].copy(), (-box[3:]).copy()
+    tot = torch.tensor([n_local], dtype=torch.int64, device=device)
+    dist.all_reduce(tot, group=group)
+    total = int(tot.item())
+    if total == 0:
+        return torch.empty((0, 4), dtype=torch.int32, device=device), 0
+    counts, status = ctx.cloudBigPartition(gmin, gmax, world)
+    if status & 1:  # PCL's overflow guard on the global box: the merge returns its input unchanged
+        counts = [0] * world
+        counts[rank] = n_local  # everything stays where it is; rank order is already global order
+    send = ctx.cloudBigRead(device=device)
+    recv, _ = _all_to_all_points(send, counts, group)
+    ctx.cloudBigReset()
+    if recv.shape[0]:
+        ctx.cloudBigAppend(recv)
+    mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax)
+    if not gather_result:
+        return mine, total
+    shards, _ = all_gather_points(mine, group)
+    return torch.cat(shards), total

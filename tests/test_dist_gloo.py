@@ -73,3 +73,97 @@ def test_two_rank_exchange_equals_single_process(tmp_path, orc):
         got_small = np.load(tmp_path / f"small_{r}.npy")
         assert np.array_equal(got_big.view(np.uint32), big.view(np.uint32))
         assert np.array_equal(got_small.view(np.uint32), small.view(np.uint32))
+
+
+# ---- partitioned merge (dist.merge_partitioned): the protocol with a CPU stand-in for the context -----
+class CpuCtx:
+    """Implements the handful of Context methods merge_partitioned uses, on the CPU oracle, so the
+    exchange logic can run under gloo without a GPU.  (Test infrastructure only.)"""
+
+    def __init__(self, orc, voxel_size):
+        self.orc, self.vs = orc, voxel_size
+        self.cloud = np.zeros(0, orc.POINT)
+
+    def cloudBigBBox(self):
+        c = self.cloud
+        if len(c) == 0:
+            return np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32), 0
+        return (np.array([c[a].min() for a in "xyz"], np.float32), np.array([c[a].max() for a in "xyz"], np.float32), len(c))
+
+    def _keys(self, gmin, gmax):
+        # PCL's index for a grid over the GLOBAL box: two corner sentinels force that box
+        aug = np.zeros(len(self.cloud) + 2, self.orc.POINT)
+        aug[: len(self.cloud)] = self.cloud
+        aug["z"] += np.float32(500)
+        for k, a in enumerate("xyz"):
+            aug[a][-2] = gmin[k] + (np.float32(500) if a == "z" else np.float32(0))
+            aug[a][-1] = gmax[k] + (np.float32(500) if a == "z" else np.float32(0))
+        keys, min_b, div_b, st = self.orc.voxel_keys(aug, [self.vs, self.vs, 1000.0])
+        return keys[:-2], div_b, st
+
+    def cloudBigPartition(self, gmin, gmax, n_parts):
+        if len(self.cloud) == 0:
+            return [0] * n_parts, 0
+        keys, div_b, st = self._keys(gmin, gmax)
+        if st:
+            return [0] * n_parts, 1
+        cells = int(div_b[0]) * int(div_b[1]) * int(div_b[2])
+        part = np.minimum(keys.astype(np.uint64) * np.uint64(n_parts) // np.uint64(cells), n_parts - 1).astype(np.int64)
+        order = np.argsort(part, kind="stable")
+        self.cloud = self.cloud[order]
+        return [int((part == p).sum()) for p in range(n_parts)], 0
+
+    def cloudBigRead(self, device=None):
+        return torch.from_numpy(self.cloud.view(np.int32).reshape(-1, 4).copy())
+
+    def cloudBigReset(self):
+        self.cloud = np.zeros(0, self.orc.POINT)
+
+    def cloudBigAppend(self, t):
+        self.cloud = np.concatenate([self.cloud, t.numpy().view(self.orc.POINT).reshape(-1)])
+
+    def finalize(self, device=None, gmin=None, gmax=None):
+        out, _ = self.orc.downsample_pt_cloud(self.cloud, self.vs, True, 1)
+        return torch.from_numpy(out.view(np.int32).reshape(-1, 4).copy())
+
+
+def _worker_partitioned(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from online_3d_reconstruction_amd import dist as o3dist
+    from online_3d_reconstruction_amd import synth
+    from oracle import orc
+    F_total, rows, cols, jump, vs = 7, 240, 400, 2, 0.05
+    Q = synth.camera_Q(rows, cols)
+    a, b = o3dist.shard_range(F_total, rank, world)
+    ctx = CpuCtx(orc, vs)
+    for i in range(a, b):
+        d, c = synth.make_frame(i, rows, cols)
+        ctx.cloud = np.concatenate([ctx.cloud, orc.create_and_transform_pt_cloud(d, c, Q, synth.make_pose(i), vs, jump_pixels=jump)[0]])
+    merged, total = o3dist.merge_partitioned(ctx, torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged.numpy().view(orc.POINT).reshape(-1))
+    np.save(os.path.join(out_dir, f"total_{rank}.npy"), np.array([total]))
+    dist.destroy_process_group()
+
+
+def test_partitioned_merge_equals_single_process(tmp_path, orc):
+    """3 ranks, 7 frames: slices exchanged all-to-all, merged locally, gathered == one-process merge"""
+    from online_3d_reconstruction_amd import synth
+    world = 3
+    mp.spawn(_worker_partitioned, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    F_total, rows, cols, jump, vs = 7, 240, 400, 2, 0.05
+    Q = synth.camera_Q(rows, cols)
+    clouds = []
+    for i in range(F_total):
+        d, c = synth.make_frame(i, rows, cols)
+        clouds.append(orc.create_and_transform_pt_cloud(d, c, Q, synth.make_pose(i), vs, jump_pixels=jump)[0])
+    big = np.concatenate(clouds)
+    small, _ = orc.downsample_pt_cloud(big, vs, True, 1)
+    for r in range(world):
+        got = np.load(tmp_path / f"merged_{r}.npy")
+        assert int(np.load(tmp_path / f"total_{r}.npy")[0]) == len(big)
+        assert len(got) == len(small) and np.array_equal(got.view(np.uint32), small.view(np.uint32))

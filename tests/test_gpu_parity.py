@@ -297,3 +297,54 @@ def test_full_size_properties(ctx):
     big = ctx.cloudBigRead()
     assert small["x"].min() >= big["x"].min() and small["x"].max() <= big["x"].max()
     assert np.abs(small["z"]).max() < 30
+
+
+# ---- multi-GPU merge pieces on one GPU: virtual ranks, exchange done by hand ---------------------------
+@pytest.mark.parametrize("world", [2, 5])
+def test_partitioned_merge_virtual_ranks(Q, orc, world):
+    """cloud_big_bbox / cloud_big_partition / finalize_global: W contexts stand in for W ranks; the
+    concatenated slice merges must equal the single-context merge over all frames, bit for bit."""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    from online_3d_reconstruction_amd.dist import shard_range
+    Qs = synth.camera_Q()
+    F = 11
+    disp, bgr = synth.make_frames(300, F, invalid_frac=0.01)
+    poses = synth.make_poses(300, F)
+    prm = o3dr.Params(jump_pixels=3, voxel_size=0.05)
+    with o3dr.Context(0, Q=Qs, params=prm) as one:
+        one.accumulateFrames(disp, bgr, poses)
+        ref = one.finalize()
+    ctxs = [o3dr.Context(0, Q=Qs, params=prm) for _ in range(world)]
+    try:
+        boxes = []
+        for r, c in enumerate(ctxs):
+            a, b = shard_range(F, r, world)
+            if b > a:
+                c.accumulateFrames(disp[a:b], bgr[a:b], poses[a:b])
+            boxes.append(c.cloudBigBBox())
+        gmin = np.min([b[0] for b in boxes], axis=0)
+        gmax = np.max([b[1] for b in boxes], axis=0)
+        sends, counts = [], []
+        for c in ctxs:
+            cnt, st = c.cloudBigPartition(gmin, gmax, world)
+            assert st == 0
+            pts = c.cloudBigRead()
+            assert sum(cnt) == len(pts)
+            counts.append(cnt)
+            sends.append(pts)
+        outs = []
+        for dst, c in enumerate(ctxs):
+            c.cloudBigReset()
+            for src in range(world):  # segments in source-rank order
+                off = sum(counts[src][:dst])
+                seg = sends[src][off: off + counts[src][dst]]
+                if len(seg):
+                    c.cloudBigAppend(seg)
+            outs.append(c.finalize(gmin=gmin, gmax=gmax))
+        got = np.concatenate(outs)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert_points_equal(got, ref, f"partitioned merge, {world} virtual ranks")
+    assert min(len(o) for o in outs) > 0  # every slice got work
