@@ -112,10 +112,19 @@ def main():
     from online_3d_reconstruction_amd import _lib as L
     from online_3d_reconstruction_amd import dist as o3dist
 
+    # rehearsal on a one-GPU box: O3DR_BENCH_REHEARSAL=1 puts every rank on cuda:0 and runs the
+    # collectives over gloo on host copies (never used for reported numbers)
+    rehearsal = os.environ.get("O3DR_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = torch.device("cpu") if rehearsal else None
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.current_stream()
 
     ctx = o3dr.Context(local_rank, Q=Q, params=o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size,
@@ -138,7 +147,7 @@ def main():
         ctx.accumulateFrames(disp, bgr, poses)
         if world > 1:
             # index-slice partition + one all-to-all + local merge + all-gather of the merged slices
-            out, m1 = o3dist.merge_partitioned(ctx, dev)
+            out, m1 = o3dist.merge_partitioned(ctx, dev, comm_device=comm_dev)
         else:
             m1, _ = ctx.cloudBigSize()
             out = ctx.finalize(device=dev)
@@ -177,7 +186,7 @@ def main():
     ctx.profileEnable(dom, False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -221,7 +230,7 @@ def main():
     result = {
         "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: gloo, one GPU)" if rehearsal else ""),
         "config": {"workload": f"synthetic {args.cols}x{args.rows} dense stereo, jump_pixels {args.jump_pixels}, "
                                f"{F} frames/GPU, voxel_size {args.voxel_size}, min_points_per_voxel {args.min_points}, "
                                "SOR off, frames resident in HBM (BASELINE.json configs[1])",

@@ -602,21 +602,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     __syncthreads();
     const uint32_t* src = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
     const int64_t base = (int64_t)tile * kSortTile;
-    const int lane = threadIdx.x & 63;
     if (base < n) {
-#pragma unroll 4
-        for (int r = 0; r < kSortRounds; ++r) {
-            const int64_t i = base + (int64_t)(threadIdx.x >> 6) * kSortWaveItems + r * kWave + lane;
-            const bool ok = i < n;
-            const uint32_t dgt = ok ? ((src[i] >> shift) & dmask) : 0u;
-            const uint64_t okb = __ballot(ok);
-            if (okb == 0) continue;
-            const int leader = __ffsll((long long)okb) - 1;
-            const uint32_t first = __shfl(dgt, leader, 64);
-            if (__ballot(ok && dgt != first) == 0) {  // whole wave in one bin (high digits): one add
-                if (lane == leader) atomicAdd(&h[first], (uint32_t)__popcll(okb));
-            } else if (ok) {
-                atomicAdd(&h[dgt], 1u);
+        // a histogram does not care which lane sees which record: 16-byte loads, 4 per lane
+        const bool vec = (((int64_t)f * cap) & 3) == 0;  // tile bases are multiples of 8192
+#pragma unroll
+        for (int r = 0; r < kSortRounds / 4; ++r) {
+            const int64_t i = base + ((int64_t)r * kSortThreads + threadIdx.x) * 4;
+            if (vec && i + 3 < n) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+                atomicAdd(&h[(v.x >> shift) & dmask], 1u);
+                atomicAdd(&h[(v.y >> shift) & dmask], 1u);
+                atomicAdd(&h[(v.z >> shift) & dmask], 1u);
+                atomicAdd(&h[(v.w >> shift) & dmask], 1u);
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    if (i + k < n) atomicAdd(&h[(src[i + k] >> shift) & dmask], 1u);
             }
         }
     }

@@ -61,7 +61,7 @@ def _all_to_all_points(send, send_counts, group=None):
     return recv, recv_counts
 
 
-def merge_partitioned(ctx, device, group=None, gather_result=True):
+def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=None):
     """The reference's final merge (pose.cpp:530) over frames sharded across ranks, without replicating it:
 
       1. all-reduce (min/max) of the ranks' cloud_big bounding boxes -> the box PCL would see;
@@ -73,16 +73,18 @@ def merge_partitioned(ctx, device, group=None, gather_result=True):
       5. all-gather of the (small) merged slices; rank order = ascending voxel index.
 
     Returns (merged [M,4] int32 tensor or this rank's slice if gather_result is False, total points merged).
-    Bit-identical to a single-GPU run over all frames."""
+    Bit-identical to a single-GPU run over all frames.  `comm_device` (rehearsal with the gloo backend
+    on one GPU): run the collectives on copies on that device instead of `device`."""
     import numpy as np
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    cdev = comm_device if comm_device is not None else device
     mn, mx, n_local = ctx.cloudBigBBox()
-    box = torch.tensor(np.concatenate([mn, -mx]), dtype=torch.float32, device=device)
+    box = torch.tensor(np.concatenate([mn, -mx]), dtype=torch.float32, device=cdev)
     dist.all_reduce(box, op=dist.ReduceOp.MIN, group=group)  # min of mins, min of (-max) = -(max of maxes)
     box = box.cpu().numpy()
     gmin, gmax = box[:3].copy(), (-box[3:]).copy()
-    tot = torch.tensor([n_local], dtype=torch.int64, device=device)
+    tot = torch.tensor([n_local], dtype=torch.int64, device=cdev)
     dist.all_reduce(tot, group=group)
     total = int(tot.item())
     if total == 0:
@@ -91,13 +93,13 @@ def merge_partitioned(ctx, device, group=None, gather_result=True):
     if status & 1:  # PCL's overflow guard on the global box: the merge returns its input unchanged
         counts = [0] * world
         counts[rank] = n_local  # everything stays where it is; rank order is already global order
-    send = ctx.cloudBigRead(device=device)
+    send = ctx.cloudBigRead(device=device).to(cdev)
     recv, _ = _all_to_all_points(send, counts, group)
     ctx.cloudBigReset()
     if recv.shape[0]:
-        ctx.cloudBigAppend(recv)
+        ctx.cloudBigAppend(recv.to(device))
     mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax)
     if not gather_result:
         return mine, total
-    shards, _ = all_gather_points(mine, group)
-    return torch.cat(shards), total
+    shards, _ = all_gather_points(mine.to(cdev), group)
+    return torch.cat(shards).to(device), total
