@@ -55,6 +55,7 @@ struct o3dr_ctx {
     double Q[16];
     bool has_Q = false;
     int max_batch = 32;
+    int single_pass = 0;  // sort variant: 1 = look-back single-pass scatter, 0 = histogram/scan/scatter per pass
 
     Workspace ws;
     size_t ws_elems = 0;   // frames*(cap+1) the per-point arrays were allocated for
@@ -141,6 +142,10 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
         size_t o_part = off;  off += align256(((TS * kMaxRadix + TG + TE) / 4096 + 4 * (size_t)F + 16) * 4);
+        size_t o_phist = off; off += align256((size_t)2048 * kMaxPasses * kMaxRadix * 4);  // partial digit histograms
+        size_t o_dst = off;   off += align256((size_t)F * kMaxPasses * kMaxRadix * 4);
+        size_t o_tick = off;  off += align256((size_t)F * kMaxPasses * 4);
+        size_t o_lb = off;    const size_t lb_bytes = align256(TS * kMaxRadix * 8); off += lb_bytes;
         size_t o_mm = off;    off += align256(MM * 4);
         size_t o_nv = off;    off += align256((size_t)F * 4);
         size_t o_nk = off;    off += align256((size_t)F * 4);
@@ -161,6 +166,15 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
         w.scan_partial = (uint32_t*)(base + o_part);
+        w.partial_hist = (uint32_t*)(base + o_phist);
+        w.digit_start = (uint32_t*)(base + o_dst);
+        w.tickets = (uint32_t*)(base + o_tick);
+        w.lb_state = (uint64_t*)(base + o_lb);
+        w.lb_bytes = lb_bytes;
+        w.epoch = 0;  // fresh (or moved) look-back words: cleared once, epochs restart
+        HIPCHK(hipMemsetAsync(w.lb_state, 0, lb_bytes, c->stream));
+        w.error_flag = (uint32_t*)(c->misc_dev + 2048);
+        w.single_pass = c->single_pass;
         w.mm = (float*)(base + o_mm);
         w.n_valid = (uint32_t*)(base + o_nv);
         w.n_kp = (uint32_t*)(base + o_nk);
@@ -239,6 +253,11 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     (void)hipMemsetAsync(c->cc_big, 0, sizeof(CloudCounters), c->stream);
     (void)hipMemsetAsync(c->cc_tmp, 0, sizeof(CloudCounters), c->stream);
     (void)hipMemsetAsync(c->stats_dev, 0, sizeof(SortStats), c->stream);
+    (void)hipMemsetAsync(c->misc_dev, 0, 4096, c->stream);
+    const char* sort_env = getenv("O3DR_SORT");
+    // "lookback": single-pass chained-scan variant (correct, but measured slower than the
+    // histogram/scan/scatter form on this workload: DESIGN.md section 4); default is the classic form
+    c->single_pass = (sort_env && strcmp(sort_env, "lookback") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
     if (env && atoi(env) > 0) c->max_batch = atoi(env) > 64 ? 64 : atoi(env);
     *out_ctx = c;
@@ -401,8 +420,10 @@ static int stage_in(o3dr_ctx* c, DevBuf& b, const void* src, size_t bytes, int m
 static int read_counters(o3dr_ctx* c, const CloudCounters* dev, CloudCounters* host)
 {
     HIPCHK(hipMemcpyAsync(c->cc_host, dev, sizeof(CloudCounters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->n_host + 2, c->misc_dev + 2048, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *host = *c->cc_host;
+    if (c->n_host[2] != 0) return fail(O3DR_ERR_HIP, "radix look-back wait timed out (internal error); results are invalid");
     return O3DR_OK;
 }
 

@@ -73,6 +73,15 @@ struct Workspace {
     uint32_t* hist = nullptr;      // frames*kMaxRadix*n_sort_tiles
     uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
     uint32_t* scan_partial = nullptr;  // chunk sums of the multi-workgroup scan
+    // single-pass (look-back) sort
+    int single_pass = 0;               // 1: k_voxel_keys_hist + k_radix_scatter<true>; 0: hist/scan/scatter per pass
+    uint32_t* partial_hist = nullptr;  // 2048*kMaxPasses*kMaxRadix  per-workgroup digit histograms of k_voxel_keys_hist
+    uint32_t* digit_start = nullptr;   // frames*kMaxPasses*kMaxRadix  exclusive digit starts per pass
+    uint64_t* lb_state = nullptr;      // (sort tiles)*kMaxRadix  chained-scan words, zeroed once at allocation
+    size_t lb_bytes = 0;
+    uint32_t* tickets = nullptr;       // frames*kMaxPasses
+    uint32_t* error_flag = nullptr;    // set when a look-back spin gives up
+    uint32_t epoch = 0;                // epoch of the last look-back launch (22 bits used)
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
     int64_t mm_stride = 0;         // slots per frame

@@ -576,6 +576,93 @@ __global__ __launch_bounds__(kPtThreads) void k_voxel_keys(const o3dr_point* __r
     }
 }
 
+// Single-pass variant: the same index computation, plus per-workgroup digit histograms for EVERY pass
+// of the frame's sort plan (the digits do not depend on record order), written as partial tables
+// (no global atomics) and folded by k_digit_starts.
+constexpr int kKeyThreads = 512;
+__global__ __launch_bounds__(kKeyThreads) void k_voxel_keys_hist(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                                 const VoxelGeom* __restrict__ geom, float z_offset,
+                                                                 int64_t cap, uint32_t* __restrict__ keys, int nblk,
+                                                                 uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[kMaxPasses * kMaxRadix];
+    const int f = blockIdx.y, blk = blockIdx.x;
+    const VoxelGeom g = geom[f];
+    if (g.overflow) return;
+    for (int i = threadIdx.x; i < kMaxPasses * kMaxRadix; i += kKeyThreads) h[i] = 0;
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+    uint32_t* dst = keys + (int64_t)f * cap;
+    const int passes = (int)g.passes, bpp = (int)g.bpp;
+    const uint32_t dmask = (1u << bpp) - 1u;
+    // contiguous slice of the frame per workgroup, in chunks of 4 x 512 points
+    const int64_t per = ((((int64_t)g.n + nblk - 1) / nblk) + kKeyThreads * 4 - 1) / (kKeyThreads * 4) * (kKeyThreads * 4);
+    const int64_t b0 = (int64_t)blk * per;
+    const int64_t b1 = (b0 + per < (int64_t)g.n) ? b0 + per : (int64_t)g.n;
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = b0; base < b1; base += kKeyThreads * 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = base + k * kKeyThreads + threadIdx.x;
+            if (i < b1) v[k] = src[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = base + k * kKeyThreads + threadIdx.x;
+            const bool ok = i < b1;
+            uint32_t key = 0;
+            if (ok) {
+                const float x = __uint_as_float(v[k].x), y = __uint_as_float(v[k].y), z = __uint_as_float(v[k].z) + z_offset;
+                const int32_t i0 = (int32_t)floorf(x * g.inv[0]) - g.min_b[0];
+                const int32_t i1 = (int32_t)floorf(y * g.inv[1]) - g.min_b[1];
+                const int32_t i2 = (int32_t)floorf(z * g.inv[2]) - g.min_b[2];
+                key = (uint32_t)i0 + (uint32_t)i1 * g.mul1 + (uint32_t)i2 * g.mul2;
+                dst[i] = key;
+            }
+            const uint64_t okb = __ballot(ok);
+            if (okb == 0) continue;
+            const int leader = __ffsll((long long)okb) - 1;
+            for (int p = 0; p < passes; ++p) {
+                const uint32_t dgt = (key >> (p * bpp)) & dmask;
+                const uint32_t first = __shfl(dgt, leader, 64);
+                if (__ballot(ok && dgt != first) == 0) {  // whole wave in one bin (high digits): one add
+                    if (lane == leader) atomicAdd(&h[p * kMaxRadix + first], (uint32_t)__popcll(okb));
+                } else if (ok) {
+                    atomicAdd(&h[p * kMaxRadix + dgt], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = partial + ((int64_t)f * nblk + blk) * (kMaxPasses * kMaxRadix);
+    const int bins = 1 << bpp;
+    for (int i = threadIdx.x; i < passes * kMaxRadix; i += kKeyThreads)
+        if ((i & (kMaxRadix - 1)) < bins) out[i] = h[i];
+}
+
+// per frame and pass: exclusive scan over the digits of the summed partial histograms; resets the tickets
+__global__ __launch_bounds__(kMaxRadix) void k_digit_starts(const uint32_t* __restrict__ partial, int nblk,
+                                                            const VoxelGeom* __restrict__ geom,
+                                                            uint32_t* __restrict__ digit_start,
+                                                            uint32_t* __restrict__ tickets)
+{
+    __shared__ uint32_t scan_lds[kMaxRadix / 64 + 1];
+    const int f = blockIdx.x;
+    const VoxelGeom g = geom[f];
+    if (threadIdx.x < kMaxPasses) tickets[f * kMaxPasses + threadIdx.x] = 0;
+    if (g.overflow) return;
+    const int bins = 1 << g.bpp;
+    for (int p = 0; p < (int)g.passes; ++p) {
+        uint32_t v = 0;
+        if ((int)threadIdx.x < bins)
+            for (int b = 0; b < nblk; ++b) v += partial[(((int64_t)f * nblk + b) * kMaxPasses + p) * kMaxRadix + threadIdx.x];
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_u32<kMaxRadix / 64>(v, scan_lds, total);
+        if ((int)threadIdx.x < bins) digit_start[((int64_t)f * kMaxPasses + p) * kMaxRadix + threadIdx.x] = excl;
+    }
+}
+
 // =================================================================================================
 // K2b — stable LSD radix sort of (voxel index, point id).
 //   PCL sorts with std::sort (order inside a voxel unspecified); the canonical order here is the
@@ -625,20 +712,42 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) dst[(int64_t)dgt * n_tiles + tile] = h[dgt];
 }
 
+// Chained-scan ("look-back") state of the single-pass variant: one 64-bit word per (tile, digit),
+//   [63:42] epoch of the launch that wrote it   [41:40] 1 = tile's own count, 2 = inclusive prefix
+//   [39:0]  value.
+// The word is written with ONE agent-scope 8-byte store and polled with agent-scope relaxed loads
+// (MI355X_MICROARCH.md, visibility: "8-B agent atomics both sides"); the epoch makes stale words
+// of earlier launches unreadable without clearing the array.  Tiles take a ticket in start order, so
+// every tile a workgroup waits for has started before it: no wait can deadlock.
+constexpr uint64_t kLbLocal = 1ull << 40, kLbIncl = 2ull << 40, kLbValueMask = (1ull << 40) - 1ull;
+constexpr uint32_t kLbSpinLimit = 1u << 22;
+
+template <bool kLookback>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
                                                                 uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
                                                                 int64_t cap, const VoxelGeom* __restrict__ geom,
                                                                 int pass, int n_tiles,
-                                                                const uint32_t* __restrict__ hist_scanned)
+                                                                const uint32_t* __restrict__ hist_scanned,
+                                                                const uint32_t* __restrict__ digit_start,
+                                                                uint64_t* __restrict__ lb_state,
+                                                                uint32_t* __restrict__ tickets, uint32_t epoch,
+                                                                uint32_t* __restrict__ error_flag)
 {
     __shared__ uint32_t wave_cnt[kSortWaves * kMaxRadix];  // per-wave digit counts -> exclusive wave prefixes
     __shared__ uint32_t local_base[kMaxRadix];             // start of each digit inside the tile's sorted order
     __shared__ uint32_t delta[kMaxRadix];                  // global start of (digit, tile) - local_base
     __shared__ uint32_t stage[kSortTile];                  // the tile's keys, then ids, in sorted order
     __shared__ uint32_t scan_lds[kSortWaves + 1];
-    const int f = blockIdx.y, tile = blockIdx.x;
+    __shared__ uint32_t ticket_lds;
+    const int f = blockIdx.y;
     const VoxelGeom g = geom[f];
     if (g.overflow || pass >= (int)g.passes) return;
+    int tile = blockIdx.x;
+    if (kLookback) {  // tiles are numbered in the order their workgroups start
+        if (threadIdx.x == 0) ticket_lds = atomicAdd(&tickets[f * kMaxPasses + pass], 1u);
+        __syncthreads();
+        tile = (int)ticket_lds;
+    }
     const uint32_t n = g.n;
     const int64_t base = (int64_t)tile * kSortTile;
     if (base >= n) return;
@@ -709,8 +818,43 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
     for (int j = 0; j < 2; ++j) {
         const int dg = 2 * threadIdx.x + j;
         if (dg < bins) {
+            uint32_t gbase;
+            if (kLookback) {
+                // publish this tile's count, fold the predecessors' words back to the nearest inclusive
+                // prefix, publish the inclusive prefix
+                uint64_t* st = lb_state + ((int64_t)f * n_tiles) * kMaxRadix;
+                const uint64_t tag = (uint64_t)epoch << 42;
+                uint64_t excl = 0;
+                if (tile > 0) {
+                    __hip_atomic_store(&st[(int64_t)tile * kMaxRadix + dg], tag | kLbLocal | (uint64_t)tot[j], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    for (int t = tile - 1; t >= 0; --t) {
+                        uint64_t wv;
+                        uint32_t spins = 0;
+                        for (;;) {
+                            wv = __hip_atomic_load(&st[(int64_t)t * kMaxRadix + dg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((wv >> 42) == (uint64_t)epoch && (wv & (kLbLocal | kLbIncl))) break;
+                            // never expected; fail loudly instead of hanging the GPU
+                            if (++spins > kLbSpinLimit ||
+                                ((spins & 1023u) == 0 && __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                                atomicOr(error_flag, 1u);
+                                wv = kLbIncl;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        excl += wv & kLbValueMask;
+                        if (wv & kLbIncl) break;
+                    }
+                }
+                __hip_atomic_store(&st[(int64_t)tile * kMaxRadix + dg], tag | kLbIncl | (excl + (uint64_t)tot[j]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                gbase = digit_start[((int64_t)f * kMaxPasses + pass) * kMaxRadix + dg] + (uint32_t)excl;
+            } else {
+                gbase = hist_scanned[(int64_t)f * kMaxRadix * n_tiles + (int64_t)dg * n_tiles + tile];
+            }
             local_base[dg] = lb;
-            delta[dg] = hist_scanned[(int64_t)f * kMaxRadix * n_tiles + (int64_t)dg * n_tiles + tile] - lb;
+            delta[dg] = gbase - lb;
         }
         lb += tot[j];
     }
@@ -1148,29 +1292,58 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     }
     uint32_t* n_keep = nullptr;
     if (!v.passthrough && cap > 0) {
-        {
-            ProfScope ps(pf, O3DR_K_KEYGEN, s);
-            k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, ws.geom,
-                                                                                    v.z_offset, cap, ws.keys[0]);
-        }
-        // always 4 launches; frames whose index needs fewer passes drop out on the device
-        const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
-        for (int pass = 0; pass < kMaxPasses; ++pass) {
-            const dim3 grid(n_sort_tiles, F);
+        const dim3 grid(n_sort_tiles, F);
+        if (ws.single_pass) {
+            // keys + all digit histograms in one read of the points; then one look-back scatter per pass
+            int nblk = 2048 / F;
+            if (nblk > 256) nblk = 256;
+            const int max_blk = cdiv64(cap, kKeyThreads * 4);
+            if (nblk > max_blk) nblk = max_blk;
+            if (nblk < 1) nblk = 1;
             {
-                ProfScope ps(pf, O3DR_K_SORT_HIST, s);
-                k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles,
-                                                          ws.hist);
+                ProfScope ps(pf, O3DR_K_KEYGEN, s);
+                k_voxel_keys_hist<<<dim3(nblk, F), kKeyThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
+                                                                       ws.keys[0], nblk, ws.partial_hist);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
-                launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, ws.geom, pass,
-                            n_sort_tiles);
+                k_digit_starts<<<F, kMaxRadix, 0, s>>>(ws.partial_hist, nblk, ws.geom, ws.digit_start, ws.tickets);
+                if (ws.epoch > 0x3ffff0u - 8u) {  // epoch field about to wrap: clear the words, restart
+                    (void)hipMemsetAsync(ws.lb_state, 0, ws.lb_bytes, s);
+                    ws.epoch = 0;
+                }
             }
-            {
+            for (int pass = 0; pass < kMaxPasses; ++pass) {
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
-                k_radix_scatter<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                             ws.geom, pass, n_sort_tiles, ws.hist);
+                k_radix_scatter<true><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                   ws.geom, pass, n_sort_tiles, nullptr, ws.digit_start,
+                                                                   ws.lb_state, ws.tickets, ++ws.epoch, ws.error_flag);
+            }
+        } else {
+            {
+                ProfScope ps(pf, O3DR_K_KEYGEN, s);
+                k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, ws.geom,
+                                                                                        v.z_offset, cap, ws.keys[0]);
+            }
+            // always 4 launches; frames whose index needs fewer passes drop out on the device
+            const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
+            for (int pass = 0; pass < kMaxPasses; ++pass) {
+                {
+                    ProfScope ps(pf, O3DR_K_SORT_HIST, s);
+                    k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles,
+                                                              ws.hist);
+                }
+                {
+                    ProfScope ps(pf, O3DR_K_OTHER, s);
+                    launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, ws.geom, pass,
+                                n_sort_tiles);
+                }
+                {
+                    ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
+                    k_radix_scatter<false><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                        ws.geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
+                                                                        nullptr, 0u, nullptr);
+                }
             }
         }
         const dim3 sgrid(n_seg_tiles, F);
@@ -1241,8 +1414,9 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
     k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
     k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, 0, n_sort_tiles, ws.hist);
     launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, 0, n_sort_tiles);
-    k_radix_scatter<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, 0,
-                                                                  n_sort_tiles, ws.hist);
+    k_radix_scatter<false><<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                         ws.geom, 0, n_sort_tiles, ws.hist, nullptr, nullptr, nullptr,
+                                                                         0u, nullptr);
     k_gather_points<<<cdiv64(cap, 256), 256, 0, s>>>(v.in, ws.vals[1], ws.geom, out);
     k_part_counts<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.keys[1], ws.geom, n_parts, counts_dev, overflow_dev);
 }
