@@ -348,3 +348,19 @@ def test_partitioned_merge_virtual_ranks(Q, orc, world):
             c.close()
     assert_points_equal(got, ref, f"partitioned merge, {world} virtual ranks")
     assert min(len(o) for o in outs) > 0  # every slice got work
+
+
+def test_config5_shape_4k_semidense(ctx, orc):
+    """BASELINE config 5 shape: 4096x2160, jump_pixels 4 (strided rows, generic load path), one frame"""
+    from online_3d_reconstruction_amd import synth
+    Qs = synth.camera_Q(2160, 4096)
+    ctx.set_camera(Qs)
+    disp, bgr = synth.make_frame(3, 2160, 4096, invalid_frac=0.02)
+    T = synth.make_pose(3)
+    ctx.set_params(_params(jump_pixels=4, voxel_size=0.05))
+    assert ctx.max_points(2160, 4096) == 530 * 891
+    got, st = ctx.createAndTransformPtCloud(disp, bgr, T, return_status=True)
+    ref, rst = orc.create_and_transform_pt_cloud(disp, bgr, Qs, T, 0.05, jump_pixels=4)
+    assert st == rst
+    assert_points_equal(got, ref, "config 5 frame")
+    ctx.set_camera(synth.camera_Q())
