@@ -73,9 +73,9 @@ typedef struct o3dr_params {
     int32_t  jump_pixels;          /* pose.h:96  jump_pixels = 10; 0 = keypoints only, 1 = dense (no keypoint pass) */
     uint32_t min_points_per_voxel; /* pose.h:108 = 1; only the combined merge uses it (pose_functions.cpp:1693) */
     int32_t  dont_downsample;      /* --dont_downsample, pose.cpp:609 */
-    int32_t  sor_enable;           /* statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686).
-                                      0 = off (the measured GPU configs); 1 is reserved and
-                                      currently returns O3DR_ERR_INVALID_ARG */
+    int32_t  sor_enable;           /* statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686:
+                                      mean_k 50, 1 sigma, active iff !combined && jump_pixels > 0).  0 = off (the
+                                      measured GPU configs); 1 = on, as in the reference */
 } o3dr_params;
 
 typedef struct o3dr_ctx o3dr_ctx; /* opaque */
@@ -142,6 +142,13 @@ int o3dr_voxel_grid(o3dr_ctx* ctx, const o3dr_point* in, int64_t n_in,
                     const float leaf[3], uint32_t min_points, float z_offset,
                     o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
                     int32_t mem);
+
+/* ---- A3b: pcl::StatisticalOutlierRemoval<PointXYZRGB> as configured at pose_functions.cpp:1679-1684 ---
+ * (setMeanK(50), setStddevMulThresh(1.0)) on its own: exact 51-nearest-neighbour search, mean neighbour
+ * distance per point, global mean + 1 sigma gate; inliers keep their order.  Clouds of <= 50 points
+ * pass through (the reference reads past its neighbour list there).  out_capacity >= n_in. */
+int o3dr_statistical_outlier_removal(o3dr_ctx* ctx, const o3dr_point* in, int64_t n_in, o3dr_point* out,
+                                     int64_t out_capacity, int64_t* n_out, int32_t mem);
 
 /* ---- A3a / A5: Pose::downsamplePtCloud (pose.h:216, pose_functions.cpp:1654-1709) --------------
  * combined == 0: per-frame mode, leaf (voxel_size/5)^3, min_points 0   (:1698)

@@ -53,6 +53,7 @@ SYMBOLS = [
     ("o3dr_transform_pt_cloud", C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32]),
     ("o3dr_reproject_transform", C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _pi64, _i32]),
     ("o3dr_voxel_grid", C.c_int, [_vp, _vp, _i64, _vp, _u32, _f, _vp, _i64, _pi64, _pu32, _i32]),
+    ("o3dr_statistical_outlier_removal", C.c_int, [_vp, _vp, _i64, _vp, _i64, _pi64, _i32]),
     ("o3dr_downsample_pt_cloud", C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_create_and_transform_pt_cloud", C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_accumulate_frames", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32]),

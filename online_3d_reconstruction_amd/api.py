@@ -198,6 +198,18 @@ class Context:
                                                   C.byref(n), C.byref(st), mem))
         return (out[: n.value], st.value) if return_status else out[: n.value]
 
+    def statisticalOutlierRemoval(self, pts):
+        """pcl::StatisticalOutlierRemoval, mean_k 50, 1 sigma (pose_functions.cpp:1679-1684)."""
+        if not _is_torch(pts):
+            pts = np.ascontiguousarray(pts, POINT)
+        pi, mem, _k = _ptr(pts)
+        n_in = int(pts.shape[0])
+        out = self._alloc_out(n_in, pts)
+        po, _, _k2 = _ptr(out)
+        n = C.c_int64(0)
+        L.check(self._lib.o3dr_statistical_outlier_removal(self._h, pi, n_in, po, max(n_in, 1), C.byref(n), mem))
+        return out[: n.value]
+
     def voxelGrid(self, pts, leaf, min_points=0, z_offset=0.0, return_status=False):
         """pcl::VoxelGrid<PointXYZRGB> as the reference configures it (pose_functions.cpp:1689-1700)."""
         if not _is_torch(pts):

@@ -62,7 +62,8 @@ struct o3dr_ctx {
     size_t ws_pts_elems = 0;
     int ws_frames = 0;
     size_t ws_emit_tiles = 0, ws_sort_tiles = 0, ws_seg_tiles = 0, ws_mm_floats = 0;
-    DevBuf ws_block, ws_pts_block;
+    DevBuf ws_block, ws_pts_block, ws_sor_block;
+    int64_t ws_sor_cap = 0;
 
     // accumulating cloud (pose.cpp:434 cloud_big)
     o3dr_point* cloud_big = nullptr;
@@ -204,6 +205,40 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
     return O3DR_OK;
 }
 
+// buffers of the statistical outlier removal (allocated on first use: the measured configs run without it)
+static int sor_ensure(o3dr_ctx* c, int64_t cap)
+{
+    if (cap < 1) cap = 1;
+    if (cap > c->ws_sor_cap) {
+        uint32_t max_cells = (uint32_t)(cap / 2 > 1024 ? cap / 2 : 1024);
+        if (max_cells > (1u << 22)) max_cells = 1u << 22;
+        size_t off = 0;
+        size_t o_xyz = off;  off += align256((size_t)cap * 16);
+        size_t o_pts = off;  off += align256((size_t)cap * 16);
+        size_t o_dist = off; off += align256((size_t)cap * 4);
+        size_t o_cs = off;   off += align256((size_t)max_cells * 4);
+        size_t o_ce = off;   off += align256((size_t)max_cells * 4);
+        size_t o_part = off; off += align256(256 * 2 * 8);
+        size_t o_geom = off; off += align256(sizeof(SorGeom));
+        size_t o_n = off;    off += 256;
+        CHK(dev_ensure(c, c->ws_sor_block, off));
+        char* base = (char*)c->ws_sor_block.p;
+        Workspace& w = c->ws;
+        w.sor_xyz = (float4*)(base + o_xyz);
+        w.sor_pts = (o3dr_point*)(base + o_pts);
+        w.sor_dist = (float*)(base + o_dist);
+        w.sor_cell_start = (uint32_t*)(base + o_cs);
+        w.sor_cell_end = (uint32_t*)(base + o_ce);
+        w.sor_partial = (double*)(base + o_part);
+        w.sor_geom = (SorGeom*)(base + o_geom);
+        w.sor_n = (uint32_t*)(base + o_n);
+        w.sor_max_cells = max_cells;
+        c->ws_sor_cap = cap;
+    }
+    return O3DR_OK;
+}
+static inline bool sor_on(const o3dr_ctx* c) { return c->params.sor_enable && c->params.jump_pixels > 0; }  // :1673
+
 extern "C" int o3dr_version(void) { return O3DR_VERSION; }
 extern "C" const char* o3dr_last_error(void) { return g_err.c_str(); }
 
@@ -271,6 +306,7 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     dev_release(c->ws_block);
     dev_release(c->ws_pts_block);
+    dev_release(c->ws_sor_block);
     dev_release(c->st_disp);
     dev_release(c->st_bgr);
     dev_release(c->st_in);
@@ -324,7 +360,6 @@ extern "C" int o3dr_set_params(o3dr_ctx* c, const o3dr_params* p)
     if (!p) return fail(O3DR_ERR_INVALID_ARG, "params is NULL");
     if (p->bounding_box < 0 || p->cutout_ratio <= 0 || p->jump_pixels < 0 || !(p->voxel_size > 0))
         return fail(O3DR_ERR_INVALID_ARG, "params out of range");
-    if (p->sor_enable) return fail(O3DR_ERR_INVALID_ARG, "sor_enable=1 is not implemented (SURVEY 8f-1)");
     c->params = *p;
     return O3DR_OK;
 }
@@ -436,11 +471,14 @@ static int zero_counters(o3dr_ctx* c, CloudCounters* dev)
 // A1 (+A2) of one frame into `dst` (device).  n_valid ends up in ws.n_valid[0].
 static int run_reproject_single(o3dr_ctx* c, const uint8_t* disp_d, int64_t disp_pitch, const uint8_t* bgr_d,
                                 int64_t bgr_pitch, int rows, int cols, const GridShape& g, const float* T,
-                                const float* kp_d, int n_kp, o3dr_point* dst)
+                                const float* kp_d, int n_kp, o3dr_point* dst, const float* T_dev = nullptr)
 {
     ReprojectArgs a;
     fill_args(c, a, disp_d, disp_pitch, 0, bgr_d, bgr_pitch, 0, rows, cols, g, 0);
-    if (T) {
+    if (T_dev) {  // pose already in HBM (one frame of a batched call)
+        a.xf_mode = 2;
+        a.poses = T_dev;
+    } else if (T) {
         a.xf_mode = 1;
         for (int i = 0; i < 12; ++i) a.T[i] = T[i];
     }
@@ -518,6 +556,13 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
         v.passthrough = 0;
         v.mm_used = (int)((g.n + kEmitTile - 1) / kEmitTile) + 1;
         v.stats = c->stats_dev;
+        if (sor_on(c)) {  // pose_functions.cpp:1673-1686 in front of the per-frame voxel grid
+            CHK(sor_ensure(c, cap));
+            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap, v.mm_used, 1.0, c->ws.sor_pts,
+                                   c->ws.sor_n);
+            v.in = c->ws.sor_pts;
+            v.n_dev = c->ws.sor_n;
+        }
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         CloudCounters cc;
@@ -605,7 +650,7 @@ static int put_bbox(o3dr_ctx* c, const float mn[3], const float mx[3])
 
 static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const float leaf[3], uint32_t min_points,
                         float z_offset, o3dr_point* out_d, int64_t* n_out, uint32_t* status,
-                        const float* gmin = nullptr, const float* gmax = nullptr)
+                        const float* gmin = nullptr, const float* gmax = nullptr, bool do_sor = false)
 {
     CHK(ws_ensure(c, 1, n_in, false));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
@@ -631,6 +676,12 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     v.passthrough = 0;
     v.mm_used = mm_used;
     v.stats = c->stats_dev;
+    if (do_sor) {
+        CHK(sor_ensure(c, n_in));
+        v.mm_used = launch_sor(&c->prof, c->stream, c->ws, in_d, c->ws.n_valid, n_in, mm_used, 1.0, c->ws.sor_pts, c->ws.sor_n);
+        v.in = c->ws.sor_pts;
+        v.n_dev = c->ws.sor_n;
+    }
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     CloudCounters cc;
@@ -640,9 +691,9 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     return O3DR_OK;
 }
 
-extern "C" int o3dr_voxel_grid(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, const float leaf[3], uint32_t min_points,
-                               float z_offset, o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
-                               int32_t mem)
+static int voxel_grid_impl(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, const float leaf[3], uint32_t min_points,
+                           float z_offset, o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
+                           int32_t mem, bool do_sor)
 {
     if (n_out) *n_out = 0;
     if (status) *status = 0;
@@ -663,7 +714,7 @@ extern "C" int o3dr_voxel_grid(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, 
     }
     int64_t m = 0;
     uint32_t st = 0;
-    CHK(voxel_single(c, (const o3dr_point*)in_d, n_in, leaf, min_points, z_offset, out_d, &m, &st));
+    CHK(voxel_single(c, (const o3dr_point*)in_d, n_in, leaf, min_points, z_offset, out_d, &m, &st, nullptr, nullptr, do_sor));
     if (mem == O3DR_MEM_HOST) {
         if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
         if (m > 0) {
@@ -673,6 +724,43 @@ extern "C" int o3dr_voxel_grid(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, 
     }
     *n_out = m;
     if (status) *status = st;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_voxel_grid(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, const float leaf[3], uint32_t min_points,
+                               float z_offset, o3dr_point* out, int64_t out_capacity, int64_t* n_out, uint32_t* status,
+                               int32_t mem)
+{
+    return voxel_grid_impl(c, in, n_in, leaf, min_points, z_offset, out, out_capacity, n_out, status, mem, false);
+}
+
+// A3b alone: pcl::StatisticalOutlierRemoval with mean_k 50, stddev_mul 1.0 (pose_functions.cpp:1679-1684)
+extern "C" int o3dr_statistical_outlier_removal(o3dr_ctx* c, const o3dr_point* in, int64_t n_in, o3dr_point* out,
+                                                int64_t out_capacity, int64_t* n_out, int32_t mem)
+{
+    if (n_out) *n_out = 0;
+    CTX_ENTER(c);
+    if (!n_out || n_in < 0 || (n_in > 0 && (!in || !out))) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    if (n_in >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "more than 2^32-1 points in one cloud");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (n_in == 0) return O3DR_OK;
+    if (out_capacity < n_in) return fail(O3DR_ERR_CAPACITY, "output must hold n_in points");
+    const void* in_d;
+    CHK(stage_in(c, c->st_in, in, (size_t)n_in * sizeof(o3dr_point), mem, &in_d));
+    CHK(ws_ensure(c, 1, n_in, false));
+    CHK(sor_ensure(c, n_in));
+    launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
+    const int used = launch_points_minmax(&c->prof, c->stream, (const o3dr_point*)in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
+    o3dr_point* dst = mem == O3DR_MEM_DEVICE ? out : c->ws.sor_pts;
+    launch_sor(&c->prof, c->stream, c->ws, (const o3dr_point*)in_d, c->ws.n_valid, n_in, used, 1.0, dst, c->ws.sor_n);
+    HIPCHK(hipGetLastError());
+    uint32_t m = 0;
+    CHK(read_u32(c, c->ws.sor_n, &m));
+    if (mem == O3DR_MEM_HOST && m > 0) {
+        HIPCHK(hipMemcpyAsync(out, dst, (size_t)m * sizeof(o3dr_point), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *n_out = (int64_t)m;
     return O3DR_OK;
 }
 
@@ -701,7 +789,8 @@ extern "C" int o3dr_downsample_pt_cloud(o3dr_ctx* c, const o3dr_point* in, int64
     float leaf[3], zo;
     uint32_t mp;
     downsample_leaf(c->params, combined, leaf, &mp, &zo);
-    return o3dr_voxel_grid(c, in, n_in, leaf, mp, zo, out, out_capacity, n_out, status, mem);
+    // statistical outlier removal iff !combinedPtCloud && jump_pixels > 0 (pose_functions.cpp:1673), when enabled
+    return voxel_grid_impl(c, in, n_in, leaf, mp, zo, out, out_capacity, n_out, status, mem, !combined && sor_on(c));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -848,11 +937,47 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         return fail(O3DR_ERR_INVALID_ARG, "frame stride smaller than a frame");
     const GridShape g = grid_shape(c->params, rows, cols);
     if (g.n == 0) return O3DR_OK;  // jump_pixels == 0 without keypoints: nothing to add
-    const int B = n_frames < c->max_batch ? n_frames : c->max_batch;
-    CHK(ws_ensure(c, B, g.n, true));
     float leaf[3], zo;
     uint32_t mp;
     downsample_leaf(c->params, 0, leaf, &mp, &zo);
+    if (sor_on(c) && !c->params.dont_downsample) {
+        // statistical outlier removal enabled: frames go through the single-cloud path one by one
+        CHK(ws_ensure(c, 1, g.n, true));
+        CHK(sor_ensure(c, g.n));
+        const void *disp_d, *bgr_d, *poses_d;
+        for (int f = 0; f < n_frames; ++f) {
+            CHK(cloud_make_room(c, g.n));
+            CHK(stage_in(c, c->st_disp, disp + (int64_t)f * disp_frame_stride, (size_t)disp_frame_stride, mem, &disp_d));
+            CHK(stage_in(c, c->st_bgr, bgr + (int64_t)f * bgr_frame_stride, (size_t)bgr_frame_stride, mem, &bgr_d));
+            CHK(stage_in(c, c->st_poses, poses + 16 * (int64_t)f, 16 * sizeof(float), mem, &poses_d));
+            CHK(run_reproject_single(c, (const uint8_t*)disp_d, disp_pitch, (const uint8_t*)bgr_d, bgr_pitch, rows, cols, g,
+                                     nullptr, nullptr, 0, c->ws.pts, (const float*)poses_d));
+            VoxelArgs v;
+            v.in = c->ws.sor_pts;
+            v.in_fstride = 0;
+            v.n_dev = c->ws.sor_n;
+            v.frames = 1;
+            v.cap = g.n;
+            v.leaf[0] = leaf[0];
+            v.leaf[1] = leaf[1];
+            v.leaf[2] = leaf[2];
+            v.min_points = mp;
+            v.z_offset = zo;
+            v.out_base = c->cloud_big;
+            v.cc = c->cc_big;
+            v.passthrough = 0;
+            v.stats = c->stats_dev;
+            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, g.n,
+                                   (int)((g.n + kEmitTile - 1) / kEmitTile) + 1, 1.0, c->ws.sor_pts, c->ws.sor_n);
+            launch_voxel_grid(&c->prof, c->stream, c->ws, v);
+            HIPCHK(hipGetLastError());
+            c->cloud_ub += g.n;
+            if (mem == O3DR_MEM_HOST) HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return O3DR_OK;
+    }
+    const int B = n_frames < c->max_batch ? n_frames : c->max_batch;
+    CHK(ws_ensure(c, B, g.n, true));
 
     for (int f0 = 0; f0 < n_frames; f0 += B) {
         const int nb = (n_frames - f0) < B ? (n_frames - f0) : B;

@@ -42,6 +42,15 @@ struct VoxelGeom {
     uint32_t bpp;         // bits per pass
 };
 
+// ---- statistical outlier removal (A3b): search grid + threshold, written by k_sor_plan / k_sor_threshold ----
+constexpr int kSorMeanK = 50;  // sor0.setMeanK(50), pose_functions.cpp:1681
+struct SorGeom {
+    float mnx, mny, inv_h, h;
+    int32_t gx, gy;
+    uint32_t n, active;
+    double threshold;
+};
+
 // ---- arguments of the fused reprojection kernels (A1 + A2) ------------------------------------
 struct ReprojectArgs {
     const uint8_t* disp;  // frame f at disp + f*disp_fstride
@@ -73,6 +82,16 @@ struct Workspace {
     uint32_t* hist = nullptr;      // frames*kMaxRadix*n_sort_tiles
     uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
     uint32_t* scan_partial = nullptr;  // chunk sums of the multi-workgroup scan
+    // statistical outlier removal (single-cloud path)
+    SorGeom* sor_geom = nullptr;
+    float4* sor_xyz = nullptr;          // cap      coordinates in cell order
+    float* sor_dist = nullptr;          // cap      mean neighbour distance per point
+    uint32_t* sor_cell_start = nullptr; // sor_max_cells
+    uint32_t* sor_cell_end = nullptr;
+    uint32_t sor_max_cells = 0;
+    double* sor_partial = nullptr;      // 256*2
+    o3dr_point* sor_pts = nullptr;      // cap      inliers
+    uint32_t* sor_n = nullptr;          // 1        inlier count
     // single-pass (look-back) sort
     int single_pass = 0;               // 1: k_voxel_keys_hist + k_radix_scatter<true>; 0: hist/scan/scatter per pass
     uint32_t* partial_hist = nullptr;  // 2048*kMaxPasses*kMaxRadix  per-workgroup digit histograms of k_voxel_keys_hist
@@ -142,6 +161,8 @@ struct VoxelArgs {
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);
 void launch_bbox(Profiler* pf, hipStream_t s, const float* mm, int used, float* out6);
+int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, const uint32_t* n_dev, int64_t cap,
+               int mm_used, double stddev_mul, o3dr_point* out, uint32_t* n_out_dev);
 void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
                       uint64_t* counts_dev, uint32_t* overflow_dev);
 

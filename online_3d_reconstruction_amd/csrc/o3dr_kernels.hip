@@ -1193,6 +1193,264 @@ __global__ void k_part_counts(const uint32_t* __restrict__ sorted_parts, const V
 }
 
 // =================================================================================================
+// A3b — pcl::StatisticalOutlierRemoval<PointXYZRGB> (pose_functions.cpp:1673-1686: mean_k 50, 1 sigma)
+//   [PCL 1.8 filters/impl/statistical_outlier_removal.hpp on KdTreeFLANN / flann::L2_Simple<float>]
+//   d2 = ((0 + dx*dx) + dy*dy) + dz*dz in fp32; the 51 smallest d2 per point (the point itself
+//   included), mean of sqrt over the 50 non-first ones in fp64, global mean/stddev in fp64, keep iff
+//   !(dist > mean + 1*stddev).  Exact k-NN: a uniform XY grid (cells sorted with the radix sort above),
+//   ring expansion, conservative stop (no unvisited column can hold a point closer than 0.999*r*h).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_sor_plan(const float* __restrict__ mm, int mm_used,
+                                                  const uint32_t* __restrict__ n_dev, uint32_t max_cells,
+                                                  SorGeom* __restrict__ sg, VoxelGeom* __restrict__ geom)
+{
+    __shared__ float red[6 * 4];
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int sidx = threadIdx.x; sidx < mm_used; sidx += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], mm[sidx * 6 + a]);
+            hi[a] = fmaxf(hi[a], mm[sidx * 6 + 3 + a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_min_f32(lo[a]), h = wave_max_f32(hi[a]);
+        if ((threadIdx.x & 63) == 0) {
+            red[(threadIdx.x >> 6) * 6 + a] = l;
+            red[(threadIdx.x >> 6) * 6 + 3 + a] = h;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    SorGeom g;
+    g.n = n_dev[0];
+    g.active = g.n > (uint32_t)kSorMeanK ? 1u : 0u;  // fewer points: the reference reads past its list; pass through
+    g.mnx = fminf(fminf(red[0], red[6]), fminf(red[12], red[18]));
+    g.mny = fminf(fminf(red[1], red[7]), fminf(red[13], red[19]));
+    const float mxx = fmaxf(fmaxf(red[3], red[9]), fmaxf(red[15], red[21]));
+    const float mxy = fmaxf(fmaxf(red[4], red[10]), fmaxf(red[16], red[22]));
+    double ex = (double)mxx - (double)g.mnx, ey = (double)mxy - (double)g.mny;
+    if (!(ex > 1e-9)) ex = 1e-9;
+    if (!(ey > 1e-9)) ey = 1e-9;
+    double h = sqrt(8.0 * ex * ey / (double)(g.n ? g.n : 1u));  // ~8 points per column
+    if (h < 1e-6) h = 1e-6;
+    int64_t gx = (int64_t)(ex / h) + 1, gy = (int64_t)(ey / h) + 1;
+    while (gx * gy > (int64_t)max_cells) {
+        h *= 1.25;
+        gx = (int64_t)(ex / h) + 1;
+        gy = (int64_t)(ey / h) + 1;
+    }
+    g.h = (float)h;
+    g.inv_h = (float)(1.0 / h);
+    g.gx = (int)gx;
+    g.gy = (int)gy;
+    g.threshold = 0.0;
+    *sg = g;
+    // sort plan for the cell ids
+    VoxelGeom v;
+    for (int a = 0; a < 3; ++a) v.inv[a] = 1.f, v.min_b[a] = 0, v.div_b[a] = 1;
+    v.mul1 = v.mul2 = 1;
+    v.n = g.n;
+    v.overflow = g.active ? 0u : 1u;  // inactive: every sort kernel returns at once
+    const uint64_t cells = (uint64_t)gx * (uint64_t)gy;
+    uint32_t nbits = cells > 1 ? 64u - (uint32_t)__clzll((long long)(cells - 1)) : 1u;
+    v.passes = (nbits + kMaxRadixBits - 1) / kMaxRadixBits;
+    v.bpp = (nbits + v.passes - 1) / v.passes;
+    geom[0] = v;
+}
+
+__device__ __forceinline__ int sor_cell(const SorGeom& g, float x, float y, int& cx, int& cy)
+{
+    cx = (int)((x - g.mnx) * g.inv_h);
+    cy = (int)((y - g.mny) * g.inv_h);
+    cx = cx < 0 ? 0 : (cx >= g.gx ? g.gx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= g.gy ? g.gy - 1 : cy);
+    return cy * g.gx + cx;
+}
+
+__global__ __launch_bounds__(256) void k_sor_cells(const o3dr_point* __restrict__ in, const SorGeom* __restrict__ sg,
+                                                   uint32_t* __restrict__ keys)
+{
+    const SorGeom g = *sg;
+    if (!g.active) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+    int cx, cy;
+    keys[i] = (uint32_t)sor_cell(g, __uint_as_float(v.x), __uint_as_float(v.y), cx, cy);
+}
+
+// after the sort: coordinates in cell order (coalesced candidate reads) and [start,end) of every cell
+__global__ __launch_bounds__(256) void k_sor_cell_table(const o3dr_point* __restrict__ in, const uint32_t* __restrict__ keys0,
+                                                        const uint32_t* __restrict__ keys1, const uint32_t* __restrict__ ids0,
+                                                        const uint32_t* __restrict__ ids1, const SorGeom* __restrict__ sg,
+                                                        const VoxelGeom* __restrict__ geom, float4* __restrict__ sxyz,
+                                                        uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_end)
+{
+    const SorGeom g = *sg;
+    if (!g.active) return;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= g.n) return;
+    const VoxelGeom vg = geom[0];
+    const uint32_t* k = (vg.passes & 1u) ? keys1 : keys0;
+    const uint32_t* id = (vg.passes & 1u) ? ids1 : ids0;
+    const uint4 v = reinterpret_cast<const uint4*>(in)[id[j]];
+    sxyz[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), 0.f);
+    const uint32_t c = k[j];
+    if (j == 0 || k[j - 1] != c) cell_start[c] = (uint32_t)j;
+    if (j + 1 == g.n || k[j + 1] != c) cell_end[c] = (uint32_t)j + 1u;
+}
+
+constexpr int kSorThreads = 128;
+__global__ __launch_bounds__(kSorThreads) void k_sor_knn(const o3dr_point* __restrict__ in, const float4* __restrict__ sxyz,
+                                                         const uint32_t* __restrict__ cell_start,
+                                                         const uint32_t* __restrict__ cell_end,
+                                                         const SorGeom* __restrict__ sg, float* __restrict__ dist)
+{
+    __shared__ float best[kSorMeanK + 1][kSorThreads];  // column per lane: conflict-free
+    const SorGeom g = *sg;
+    if (!g.active) return;
+    const int64_t i = (int64_t)blockIdx.x * kSorThreads + threadIdx.x;
+    if (i >= g.n) return;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k <= kSorMeanK; ++k) best[k][t] = __builtin_huge_valf();
+    const uint4 qv = reinterpret_cast<const uint4*>(in)[i];
+    const float qx = __uint_as_float(qv.x), qy = __uint_as_float(qv.y), qz = __uint_as_float(qv.z);
+    int cx, cy;
+    sor_cell(g, qx, qy, cx, cy);
+    float worst = __builtin_huge_valf();
+    const int rmax = g.gx > g.gy ? g.gx : g.gy;
+    for (int r = 0; r <= rmax; ++r) {
+        for (int yy = cy - r; yy <= cy + r; ++yy) {
+            if (yy < 0 || yy >= g.gy) continue;
+            const bool edge_row = (yy == cy - r) || (yy == cy + r);
+            const int step = edge_row ? 1 : (2 * r > 0 ? 2 * r : 1);
+            for (int xx = cx - r; xx <= cx + r; xx += step) {
+                if (xx < 0 || xx >= g.gx) continue;
+                const int c = yy * g.gx + xx;
+                const uint32_t s1 = cell_end[c];
+                for (uint32_t sidx = cell_start[c]; sidx < s1; ++sidx) {
+                    const float4 p = sxyz[sidx];
+                    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                    const float d = ((0.0f + dx * dx) + dy * dy) + dz * dz;
+                    if (d < worst) {  // insert into the ascending list
+                        int j = kSorMeanK;
+                        while (j > 0) {
+                            const float b = best[j - 1][t];
+                            if (!(b > d)) break;
+                            best[j][t] = b;
+                            --j;
+                        }
+                        best[j][t] = d;
+                        worst = best[kSorMeanK][t];
+                    }
+                }
+            }
+        }
+        const double bound = 0.999 * (double)r * (double)g.h;
+        if (worst < __builtin_huge_valf() && (double)worst <= bound * bound) break;
+    }
+    double dist_sum = 0.0;
+    for (int k = 1; k <= kSorMeanK; ++k) dist_sum += sqrt((double)best[k][t]);
+    dist[i] = (float)(dist_sum / (double)kSorMeanK);
+}
+
+// sum and sum of squares (float product like PCL, fp64 sums): fixed-shape two-level reduction
+__global__ __launch_bounds__(256) void k_sor_partial(const float* __restrict__ dist, const SorGeom* __restrict__ sg,
+                                                     double* __restrict__ partial /*[blocks][2]*/)
+{
+    __shared__ double red[2 * 4];
+    const SorGeom g = *sg;
+    double s = 0.0, q = 0.0;
+    if (g.active) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * 256) {
+            const float d = dist[i];
+            s += (double)d;
+            q += (double)(d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[(threadIdx.x >> 6) * 2] = s;
+        red[(threadIdx.x >> 6) * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (red[0] + red[2]) + (red[4] + red[6]);
+        partial[2 * blockIdx.x + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+__global__ void k_sor_threshold(const double* __restrict__ partial, int blocks, double stddev_mul, SorGeom* __restrict__ sg)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sum = 0.0, sq = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        sum += partial[2 * b];
+        sq += partial[2 * b + 1];
+    }
+    const double n = (double)sg->n;
+    const double mean = sum / n;
+    const double variance = (sq - sum * sum / n) / (n - 1.0);
+    sg->threshold = mean + stddev_mul * sqrt(variance);
+}
+
+// ordered compaction of the inliers (count per 1024-point tile, scan, emit) + their bounding boxes
+__global__ __launch_bounds__(256) void k_sor_count(const float* __restrict__ dist, const SorGeom* __restrict__ sg,
+                                                   uint32_t* __restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[4];
+    const SorGeom g = *sg;
+    uint32_t c = 0;
+    const int64_t base = (int64_t)blockIdx.x * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < g.n) c += (!g.active || !((double)dist[i] > g.threshold)) ? 1u : 0u;
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+__global__ __launch_bounds__(256) void k_sor_emit(const o3dr_point* __restrict__ in, const float* __restrict__ dist,
+                                                  const SorGeom* __restrict__ sg, const uint32_t* __restrict__ tile_off,
+                                                  o3dr_point* __restrict__ out, int64_t mm_stride, float* __restrict__ mm)
+{
+    __shared__ uint32_t scan_lds[5];
+    __shared__ float mm_lds[6 * 4];
+    const SorGeom g = *sg;
+    const int64_t base = (int64_t)blockIdx.x * 1024;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    bool any = false;
+    uint32_t off = tile_off[blockIdx.x];
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const bool keep = (i < g.n) && (!g.active || !((double)dist[i] > g.threshold));
+        uint32_t total;
+        const uint32_t pos = block_excl_scan_u32<4>(keep ? 1u : 0u, scan_lds, total);
+        if (keep) {
+            const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+            reinterpret_cast<uint4*>(out)[off + pos] = v;
+            const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z);
+            lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+            lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+            lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+            any = true;
+        }
+        off += total;
+    }
+    block_minmax_store<4>(lo, hi, any, mm_lds, mm + (int64_t)blockIdx.x * 6);
+}
+
+// =================================================================================================
 // launchers
 // =================================================================================================
 static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -1419,6 +1677,40 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
                                                                          0u, nullptr);
     k_gather_points<<<cdiv64(cap, 256), 256, 0, s>>>(v.in, ws.vals[1], ws.geom, out);
     k_part_counts<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.keys[1], ws.geom, n_parts, counts_dev, overflow_dev);
+}
+
+// Statistical outlier removal of ONE cloud (`in`, count in n_dev[0], at most cap points, bounding boxes in
+// ws.mm slots [0, mm_used)).  Kept points -> out (same order), their count -> n_out_dev[0], their
+// bounding boxes -> ws.mm slots [0, returned value).
+int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, const uint32_t* n_dev, int64_t cap,
+               int mm_used, double stddev_mul, o3dr_point* out, uint32_t* n_out_dev)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    const int n_sort_tiles = cdiv64(cap, kSortTile);
+    const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
+    const int n_tiles = cdiv64(cap, 1024);
+    k_sor_plan<<<1, 256, 0, s>>>(ws.mm, mm_used, n_dev, ws.sor_max_cells, ws.sor_geom, ws.geom);
+    (void)hipMemsetAsync(ws.sor_cell_start, 0, (size_t)ws.sor_max_cells * 4, s);
+    (void)hipMemsetAsync(ws.sor_cell_end, 0, (size_t)ws.sor_max_cells * 4, s);
+    k_sor_cells<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.sor_geom, ws.keys[0]);
+    for (int pass = 0; pass < kMaxPasses; ++pass) {
+        k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
+        launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
+        k_radix_scatter<false><<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                             ws.geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
+                                                                             nullptr, 0u, nullptr);
+    }
+    k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
+                                                     ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);
+    k_sor_knn<<<cdiv64(cap, kSorThreads), kSorThreads, 0, s>>>(in, ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end, ws.sor_geom,
+                                                              ws.sor_dist);
+    constexpr int kStatBlocks = 256;
+    k_sor_partial<<<kStatBlocks, 256, 0, s>>>(ws.sor_dist, ws.sor_geom, ws.sor_partial);
+    k_sor_threshold<<<1, 1, 0, s>>>(ws.sor_partial, kStatBlocks, stddev_mul, ws.sor_geom);
+    k_sor_count<<<n_tiles, 256, 0, s>>>(ws.sor_dist, ws.sor_geom, ws.tile_cnt);
+    launch_scan(s, ws.tile_cnt, n_tiles, n_tiles, 1, n_out_dev, nullptr, ws.scan_partial);
+    k_sor_emit<<<n_tiles, 256, 0, s>>>(in, ws.sor_dist, ws.sor_geom, ws.tile_cnt, out, ws.mm_stride, ws.mm);
+    return n_tiles;
 }
 
 }  // namespace o3dr

@@ -75,6 +75,7 @@ public:
     int cutout_ratio = 8;
     bool dont_downsample = false, downsample = false, log_stuff = false, only_MAVLink = true, dont_icp = true;
     bool reference_fanout = false;  // run A6 through createAndTransformPtCloud on 7 host threads
+    bool sor = false;               // statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686)
     std::array<double, 16> Q{};
     std::string calib_file = "cam13calib.yml";
     std::string dataFilesPrefix = "data_files/", imagePrefix = "images/", disparityPrefix = "disparities/";

@@ -52,6 +52,7 @@ void Pose::push_params(o3dr_ctx* c)
     p.jump_pixels = jump_pixels;
     p.min_points_per_voxel = min_points_per_voxel;
     p.dont_downsample = dont_downsample ? 1 : 0;
+    p.sor_enable = sor ? 1 : 0;
     chk(o3dr_set_params(c, &p), "o3dr_set_params");
     chk(o3dr_set_camera(c, Q.data()), "o3dr_set_camera");
 }
@@ -383,7 +384,7 @@ PointCloud::Ptr Pose::read_PLY_File(string point_cloud_filename)
 void Pose::printUsage()
 {
     cout << "./pose first_img last_img [--voxel_size m] [--jump_pixels n] [--min_points_per_voxel n] [--seq_len n]\n"
-            "       [--dont_downsample] [--log 0|1] [--only_MAVLink] [--dont_icp] [--reference_fanout]\n"
+            "       [--dont_downsample] [--log 0|1] [--only_MAVLink] [--dont_icp] [--reference_fanout] [--sor 0|1]\n"
             "       [--data_dir d/] [--image_dir d/] [--disparity_dir d/] [--output_dir d/] [--calib_file f] [--device n]\n"
             "./pose --downsample file.ply [--voxel_size m] [--min_points_per_voxel n]\n"
             "Pose estimation (ORB matching, ICP), visualisation and the mesh/segment tools are not part of this build.\n";
@@ -414,6 +415,7 @@ int Pose::parseCmdArgs(int argc, char** argv)
         else if (a == "--only_MAVLink") only_MAVLink = true;
         else if (a == "--dont_icp") dont_icp = true;
         else if (a == "--reference_fanout") reference_fanout = true;
+        else if (a == "--sor") sor = atoi(need(i)) != 0;
         else if (a == "--data_dir") dataFilesPrefix = need(i);
         else if (a == "--image_dir") imagePrefix = need(i);
         else if (a == "--disparity_dir") disparityPrefix = need(i);

@@ -333,3 +333,135 @@ int64_t orc_create_and_transform_pt_cloud(const uint8_t* disp, int64_t disp_pitc
     }
     return orc_downsample_pt_cloud(tr, n, voxel_size, 0, 0, order, out, status);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * A3b: pcl::StatisticalOutlierRemoval<PointXYZRGB>::applyFilterIndices
+ * [PCL 1.8 filters/impl/statistical_outlier_removal.hpp], called at pose_functions.cpp:1679-1684 with
+ * mean_k = 50, stddev_mul = 1.0, on an unorganised cloud (height 1) => pcl::search::KdTree ->
+ * KdTreeFLANN, exact search, flann::L2_Simple<float>:
+ *     d2 = ((0 + dx*dx) + dy*dy) + dz*dz           (float, dx = query - data)
+ *   nearestKSearch(i, mean_k + 1): the mean_k+1 smallest d2 in ascending order (entry 0 is the query)
+ *   distances[i] = float( sum_{k=1..mean_k} sqrt(double(d2[k])) / mean_k )            (double sum)
+ *   sum += distances[i];  sq_sum += distances[i]*distances[i]  (float product, double sums, index order)
+ *   mean = sum/n; variance = (sq_sum - sum*sum/n)/(n-1); threshold = mean + stddev_mul*sqrt(variance)
+ *   keep i  iff  !(distances[i] > threshold)
+ * Which of several equidistant neighbours the kd-tree returns does not matter: only the distance
+ * values enter.  With n <= mean_k the reference reads past the neighbour list (undefined); here such
+ * clouds pass through unfiltered.
+ * The neighbour search below is a uniform XY grid with ring expansion and a conservative stop
+ * (no unvisited column can hold a point closer than 0.999*r*h); it is exact for any cell size.
+ * ---------------------------------------------------------------------------------------------- */
+static inline float sor_d2(const orc_point* q, const orc_point* p)
+{
+    const float dx = q->x - p->x, dy = q->y - p->y, dz = q->z - p->z;
+    return ((0.0f + dx * dx) + dy * dy) + dz * dz;
+}
+/* keep the kk smallest values of a stream in ascending order */
+static inline void sor_insert(float* best, int kk, float d)
+{
+    if (!(d < best[kk - 1])) return;
+    int j = kk - 1;
+    while (j > 0 && best[j - 1] > d) {
+        best[j] = best[j - 1];
+        --j;
+    }
+    best[j] = d;
+}
+
+int64_t orc_statistical_outlier_removal(const orc_point* in, int64_t n, int32_t mean_k, double stddev_mul,
+                                        orc_point* out, float* distances_out, int32_t brute)
+{
+    if (n <= 0) return 0;
+    if (n <= mean_k || mean_k < 1) {
+        if (out != in) memmove(out, in, (size_t)n * sizeof(orc_point));
+        if (distances_out) memset(distances_out, 0, (size_t)n * sizeof(float));
+        return n;
+    }
+    const int kk = mean_k + 1;
+    float* dist = (float*)malloc((size_t)n * sizeof(float));
+    float* best = (float*)malloc((size_t)kk * sizeof(float));
+
+    /* grid over XY */
+    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+    for (int64_t i = 0; i < n; ++i) {
+        if (in[i].x < mnx) mnx = in[i].x;
+        if (in[i].x > mxx) mxx = in[i].x;
+        if (in[i].y < mny) mny = in[i].y;
+        if (in[i].y > mxy) mxy = in[i].y;
+    }
+    double ex = (double)mxx - mnx, ey = (double)mxy - mny;
+    double h = sqrt(8.0 * (ex > 1e-9 ? ex : 1e-9) * (ey > 1e-9 ? ey : 1e-9) / (double)n);
+    if (h < 1e-6) h = 1e-6;
+    int64_t gx = (int64_t)(ex / h) + 1, gy = (int64_t)(ey / h) + 1;
+    while (gx * gy > ((int64_t)1 << 24)) {
+        h *= 1.5;
+        gx = (int64_t)(ex / h) + 1;
+        gy = (int64_t)(ey / h) + 1;
+    }
+    int32_t* cell_of = NULL;
+    int64_t* start = NULL;
+    int32_t* order = NULL;
+    if (!brute) {
+        cell_of = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+        start = (int64_t*)calloc((size_t)(gx * gy + 1), sizeof(int64_t));
+        order = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t cx = (int64_t)(((double)in[i].x - mnx) / h), cy = (int64_t)(((double)in[i].y - mny) / h);
+            if (cx >= gx) cx = gx - 1;
+            if (cy >= gy) cy = gy - 1;
+            cell_of[i] = (int32_t)(cy * gx + cx);
+            start[cell_of[i] + 1]++;
+        }
+        for (int64_t c = 0; c < gx * gy; ++c) start[c + 1] += start[c];
+        int64_t* fill = (int64_t*)malloc((size_t)(gx * gy) * sizeof(int64_t));
+        memcpy(fill, start, (size_t)(gx * gy) * sizeof(int64_t));
+        for (int64_t i = 0; i < n; ++i) order[fill[cell_of[i]]++] = (int32_t)i;
+        free(fill);
+    }
+
+    for (int64_t i = 0; i < n; ++i) {
+        for (int k = 0; k < kk; ++k) best[k] = FLT_MAX;
+        if (brute) {
+            for (int64_t j = 0; j < n; ++j) sor_insert(best, kk, sor_d2(&in[i], &in[j]));
+        } else {
+            const int64_t cx = cell_of[i] % gx, cy = cell_of[i] / gx;
+            const int64_t rmax = (gx > gy ? gx : gy);
+            for (int64_t r = 0; r <= rmax; ++r) {
+                for (int64_t yy = cy - r; yy <= cy + r; ++yy) {
+                    if (yy < 0 || yy >= gy) continue;
+                    const int64_t step = (yy == cy - r || yy == cy + r) ? 1 : 2 * r; /* ring: full rows top/bottom, ends otherwise */
+                    for (int64_t xx = cx - r; xx <= cx + r; xx += (step > 0 ? step : 1)) {
+                        if (xx < 0 || xx >= gx) continue;
+                        const int64_t c = yy * gx + xx;
+                        for (int64_t s = start[c]; s < start[c + 1]; ++s) sor_insert(best, kk, sor_d2(&in[i], &in[order[s]]));
+                    }
+                }
+                /* every unvisited column is more than r*h away in x or y (cell rounding covered by 0.999) */
+                const double bound = 0.999 * (double)r * h;
+                if (best[kk - 1] < FLT_MAX && (double)best[kk - 1] <= bound * bound) break;
+            }
+        }
+        double dist_sum = 0.0;
+        for (int k = 1; k < kk; ++k) dist_sum += sqrt((double)best[k]);
+        dist[i] = (float)(dist_sum / mean_k);
+    }
+    double sum = 0, sq_sum = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        sum += dist[i];
+        sq_sum += dist[i] * dist[i]; /* float product, as in PCL */
+    }
+    const double mean = sum / (double)n;
+    const double variance = (sq_sum - sum * sum / (double)n) / ((double)n - 1);
+    const double stddev = sqrt(variance);
+    const double threshold = mean + stddev_mul * stddev;
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (!(dist[i] > threshold)) out[m++] = in[i];
+    if (distances_out) memcpy(distances_out, dist, (size_t)n * sizeof(float));
+    free(dist);
+    free(best);
+    free(cell_of);
+    free(start);
+    free(order);
+    return m;
+}

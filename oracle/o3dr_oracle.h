@@ -46,6 +46,14 @@ void orc_transform_pt_cloud(const orc_point* in, int64_t n, const float T[16], o
 int64_t orc_voxel_grid(const orc_point* in, int64_t n, const float leaf[3], uint32_t min_points,
                        int32_t order, orc_point* out, uint32_t* status);
 
+/* A3b — pcl::StatisticalOutlierRemoval<PointXYZRGB> as configured at pose_functions.cpp:1679-1684
+ * (setMeanK(50), setStddevMulThresh(1.0)); exact k-nearest-neighbour search like PCL's KdTreeFLANN.
+ * Returns the number of points kept (input order preserved); distances_out (optional, n floats)
+ * receives the mean neighbour distance of every input point.  brute != 0 forces the O(n^2) search
+ * (self-check of the grid search in the tests). */
+int64_t orc_statistical_outlier_removal(const orc_point* in, int64_t n, int32_t mean_k, double stddev_mul,
+                                        orc_point* out, float* distances_out, int32_t brute);
+
 /* A3a/A5 — Pose::downsamplePtCloud, pose_functions.cpp:1654-1709 (statistical outlier removal,
  * :1673-1686, is not applied: see SURVEY.md section 8a row A3b). */
 int64_t orc_downsample_pt_cloud(const orc_point* in, int64_t n, double voxel_size, int32_t combined,

@@ -46,6 +46,8 @@ def lib():
         L.orc_create_and_transform_pt_cloud.restype = i64
         L.orc_create_and_transform_pt_cloud.argtypes = [vp, i64, vp, i64, i32, i32, vp, i32, i32, dbl, i32,
                                                         vp, i32, vp, dbl, i32, i32, vp, vp, vp]
+        L.orc_statistical_outlier_removal.restype = i64
+        L.orc_statistical_outlier_removal.argtypes = [vp, i64, i32, dbl, vp, vp, i32]
         L.orc_voxel_keys.restype = u32
         L.orc_voxel_keys.argtypes = [vp, i64, vp, vp, vp, vp]
         _lib = L
@@ -144,3 +146,12 @@ def voxel_keys(pts, leaf):
     div_b = np.zeros(3, np.int32)
     st = lib().orc_voxel_keys(_p(pts), len(pts), _p(leaf), _p(keys), _p(min_b), _p(div_b))
     return keys[:len(pts)], min_b, div_b, st
+
+
+def statistical_outlier_removal(pts, mean_k=50, stddev_mul=1.0, brute=False):
+    """(kept points, mean neighbour distance of every input point) — pose_functions.cpp:1679-1684"""
+    pts = np.ascontiguousarray(pts, POINT)
+    out = np.empty(max(len(pts), 1), POINT)
+    dist = np.zeros(max(len(pts), 1), np.float32)
+    n = lib().orc_statistical_outlier_removal(_p(pts), len(pts), mean_k, float(stddev_mul), _p(out), _p(dist), int(bool(brute)))
+    return out[:n].copy(), dist[:len(pts)]

@@ -241,3 +241,20 @@ def test_empty_inputs(orc, Q):
     assert len(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1)) == 0
     out, st = orc.voxel_grid(np.zeros(0, orc.POINT), [0.1, 0.1, 0.1])
     assert len(out) == 0 and st == 0
+
+
+def test_sor_grid_search_equals_brute_force(orc):
+    """the oracle's own k-NN grid search against the O(n^2) search, and the textbook definition in numpy"""
+    pts = random_cloud(1500, 9, extent=(0.6, 0.4, 0.02))
+    a, da = orc.statistical_outlier_removal(pts, brute=True)
+    b, db = orc.statistical_outlier_removal(pts)
+    assert np.array_equal(da, db) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    xyz = np.stack([pts["x"], pts["y"], pts["z"]], 1)
+    d = xyz[:, None, :] - xyz[None, :, :]
+    d2 = ((np.float32(0) + d[..., 0] * d[..., 0]) + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]  # fp32, FLANN's order
+    d2.sort(axis=1)
+    mean_d = (np.sqrt(d2[:, 1:51].astype(np.float64)).sum(axis=1) / 50).astype(np.float32)
+    assert np.abs(mean_d - da).max() <= 1e-7  # numpy sums pairwise; the oracle sums sequentially
+    thr = mean_d.astype(np.float64).mean() + mean_d.astype(np.float64).std(ddof=1)
+    keep = ~(mean_d > thr)
+    assert abs(int(keep.sum()) - len(a)) <= 1
