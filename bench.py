@@ -48,7 +48,7 @@ def generate_frames(start, count, rows, cols, invalid, workers):
     return disp, bgr
 
 
-def cpu_baseline(disp, bgr, poses, Q, voxel_size, jump, threads, n_frames):
+def cpu_baseline(disp, bgr, poses, Q, voxel_size, jump, threads, n_frames, sor=False):
     """The CPU oracle (a port of the reference arithmetic, oracle/) timed on this host: A6 for
     n_frames frames with the reference's own fan-out of `threads` frame-parallel workers
     (pose.cpp:392-413), then the combined merge.  Statistical outlier removal off, as on the GPU."""
@@ -56,7 +56,10 @@ def cpu_baseline(disp, bgr, poses, Q, voxel_size, jump, threads, n_frames):
     orc.lib()
 
     def one(i):
-        return orc.create_and_transform_pt_cloud(disp[i], bgr[i], Q, poses[i], voxel_size, jump_pixels=jump)[0]
+        if not sor:
+            return orc.create_and_transform_pt_cloud(disp[i], bgr[i], Q, poses[i], voxel_size, jump_pixels=jump)[0]
+        world = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp[i], bgr[i], Q, jump_pixels=jump), poses[i])
+        return orc.downsample_pt_cloud(orc.statistical_outlier_removal(world)[0], voxel_size, False, 1)[0]
 
     t0 = time.perf_counter()
     if threads > 1:
@@ -82,6 +85,8 @@ def main():
     ap.add_argument("--voxel-size", type=float, default=0.05)
     ap.add_argument("--min-points", type=int, default=1)
     ap.add_argument("--invalid-frac", type=float, default=0.0)
+    ap.add_argument("--sor", action="store_true", help="statistical outlier removal on (the reference's full per-frame "
+                                                      "path, pose_functions.cpp:1673-1686); off in the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand the library HOST buffers (frames cross PCIe inside the timed region); reported as "
@@ -131,7 +136,7 @@ def main():
     stream = torch.cuda.current_stream()
 
     ctx = o3dr.Context(local_rank, Q=Q, params=o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size,
-                                                          min_points_per_voxel=args.min_points), stream=stream)
+                                                          min_points_per_voxel=args.min_points, sor_enable=args.sor), stream=stream)
     if args.host_inputs:
         disp, bgr, poses = disp_h, bgr_h, poses_h
     else:
@@ -239,7 +244,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: gloo, one GPU)" if rehearsal else ""),
         "config": {"workload": f"synthetic {args.cols}x{args.rows} dense stereo, jump_pixels {args.jump_pixels}, "
                                f"{F} frames/GPU, voxel_size {args.voxel_size}, min_points_per_voxel {args.min_points}, "
-                               "SOR off, frames resident in HBM (BASELINE.json configs[1])",
+                               f"SOR {'on' if args.sor else 'off'}, frames resident in HBM (BASELINE.json configs[1])",
                    "frames_per_gpu": F, "rows": args.rows, "cols": args.cols, "jump_pixels": args.jump_pixels,
                    "voxel_size": args.voxel_size, "parallelism": f"frame-sharded x{world}"},
         "mpoints_per_sec_into_global_cloud": round(m1_total * args.steps / dt / 1e6, 2),
@@ -253,9 +258,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nf = min(args.cpu_frames, F)
-        v7, t7 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, args.cpu_threads, nf)
+        v7, t7 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, args.cpu_threads, nf, args.sor)
         n1 = min(8, F)
-        v1, t1 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, 1, n1)
+        v1, t1 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, 1, n1, args.sor)
         result["cpu_baseline"] = {"value": round(v7, 3), "unit": "frames/s", "cores": args.cpu_threads, "kind": "port",
                                   "sample": f"first {nf} frames of the same workload through the C oracle (A6 per frame on "
                                             f"{args.cpu_threads} frame-parallel threads as pose.cpp:392-413, then the combined "
