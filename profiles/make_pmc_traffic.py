@@ -20,7 +20,8 @@ def load(d, counter):
     for path in glob.glob(f"{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
-                out[r["Kernel_Name"].split("(")[0].replace("o3dr::k_", "")].append(float(r["Counter_Value"]))
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("o3dr::k_", "").split("<")[0]
+                out[name].append(float(r["Counter_Value"]))
     return out
 
 
