@@ -16,7 +16,7 @@ import json
 import os
 import sys
 import time
-from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
@@ -50,25 +50,13 @@ def generate_frames(start, count, rows, cols, invalid, workers):
 
 def cpu_baseline(disp, bgr, poses, Q, voxel_size, jump, threads, n_frames, sor=False):
     """The CPU oracle (a port of the reference arithmetic, oracle/) timed on this host: A6 for
-    n_frames frames with the reference's own fan-out of `threads` frame-parallel workers
-    (pose.cpp:392-413), then the combined merge.  Statistical outlier removal off, as on the GPU."""
+    n_frames frames on `threads` frame-parallel POSIX threads — the reference's own fan-out
+    (pose.cpp:392-413) — appended in frame order, then the combined merge (pose.cpp:530)."""
     from oracle import orc
     orc.lib()
-
-    def one(i):
-        if not sor:
-            return orc.create_and_transform_pt_cloud(disp[i], bgr[i], Q, poses[i], voxel_size, jump_pixels=jump)[0]
-        world = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp[i], bgr[i], Q, jump_pixels=jump), poses[i])
-        return orc.downsample_pt_cloud(orc.statistical_outlier_removal(world)[0], voxel_size, False, 1)[0]
-
     t0 = time.perf_counter()
-    if threads > 1:
-        with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C oracle
-            clouds = list(ex.map(one, range(n_frames)))
-    else:
-        clouds = [one(i) for i in range(n_frames)]
-    big = np.concatenate(clouds)
-    orc.downsample_pt_cloud(big, voxel_size, True, 1)
+    orc.run_frames(disp[:n_frames], bgr[:n_frames], Q, poses[:n_frames], voxel_size, jump_pixels=jump, sor=sor,
+                   threads=threads, want_clouds=False)
     dt = time.perf_counter() - t0
     return n_frames / dt, dt
 
@@ -91,7 +79,7 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand the library HOST buffers (frames cross PCIe inside the timed region); reported as "
                          "metric frames_per_sec_pcie_inclusive, never the headline value")
-    ap.add_argument("--cpu-frames", type=int, default=56)
+    ap.add_argument("--cpu-frames", type=int, default=200)
     ap.add_argument("--cpu-threads", type=int, default=7)
     ap.add_argument("--gen-workers", type=int, default=min(16, os.cpu_count() or 1))
     args = ap.parse_args()
@@ -259,7 +247,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nf = min(args.cpu_frames, F)
         v7, t7 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, args.cpu_threads, nf, args.sor)
-        n1 = min(8, F)
+        n1 = min(100, F)
         v1, t1 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, 1, n1, args.sor)
         result["cpu_baseline"] = {"value": round(v7, 3), "unit": "frames/s", "cores": args.cpu_threads, "kind": "port",
                                   "sample": f"first {nf} frames of the same workload through the C oracle (A6 per frame on "

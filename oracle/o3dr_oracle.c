@@ -19,6 +19,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -463,5 +464,100 @@ int64_t orc_statistical_outlier_removal(const orc_point* in, int64_t n, int32_t 
     free(cell_of);
     free(start);
     free(order);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A7: the fan-out of pose.cpp:365-434 (batches of frame-parallel threads, results appended in frame
+ * order) followed by the combined merge of pose.cpp:530.  Used as the timed CPU baseline.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct frame_job {
+    const uint8_t *disp, *bgr;
+    int64_t disp_fstride, disp_pitch, bgr_fstride, bgr_pitch;
+    int32_t rows, cols, bb, cs, jump, n_frames, sor;
+    const double* Q;
+    double min_disp, voxel_size;
+    const float* poses;
+    orc_point** out;
+    int64_t* out_n;
+    int64_t cap;
+    volatile int32_t* next;
+} frame_job;
+
+static void* frame_worker(void* arg)
+{
+    frame_job* j = (frame_job*)arg;
+    orc_point* scratch = (orc_point*)malloc((size_t)(2 * j->cap + 1) * sizeof(orc_point));
+    orc_point* tmp = (orc_point*)malloc((size_t)(j->cap + 1) * sizeof(orc_point));
+    for (;;) {
+        const int32_t f = __sync_fetch_and_add(j->next, 1);
+        if (f >= j->n_frames) break;
+        const uint8_t* d = j->disp + (int64_t)f * j->disp_fstride;
+        const uint8_t* c = j->bgr + (int64_t)f * j->bgr_fstride;
+        const float* T = j->poses + 16 * (int64_t)f;
+        int64_t n;
+        if (!j->sor) {
+            n = orc_create_and_transform_pt_cloud(d, j->disp_pitch, c, j->bgr_pitch, j->rows, j->cols, j->Q, j->bb, j->cs,
+                                                  j->min_disp, j->jump, NULL, 0, T, j->voxel_size, 0, ORC_ORDER_STABLE,
+                                                  scratch, tmp, NULL);
+        } else {
+            const int64_t n0 = orc_create_single_img_pt_cloud(d, j->disp_pitch, c, j->bgr_pitch, j->rows, j->cols, j->Q, j->bb,
+                                                              j->cs, j->min_disp, j->jump, NULL, 0, scratch);
+            orc_transform_pt_cloud(scratch, n0, T, scratch + n0);
+            const int64_t n1 = j->jump > 0 ? orc_statistical_outlier_removal(scratch + n0, n0, 50, 1.0, scratch, NULL, 0) : n0;
+            n = orc_downsample_pt_cloud(j->jump > 0 ? scratch : scratch + n0, n1, j->voxel_size, 0, 0, ORC_ORDER_STABLE, tmp, NULL);
+        }
+        j->out[f] = (orc_point*)malloc((size_t)(n + 1) * sizeof(orc_point));
+        memcpy(j->out[f], tmp, (size_t)n * sizeof(orc_point));
+        j->out_n[f] = n;
+    }
+    free(scratch);
+    free(tmp);
+    return NULL;
+}
+
+int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_pitch, const uint8_t* bgr,
+                       int64_t bgr_fstride, int64_t bgr_pitch, int32_t rows, int32_t cols, const double Q[16],
+                       int32_t bounding_box, int32_t cols_start_aft_cutout, double min_disparity,
+                       int32_t jump_pixels, const float* poses, int32_t n_frames, double voxel_size,
+                       uint32_t min_points_per_voxel, int32_t sor, int32_t threads, orc_point* cloud_big_out,
+                       int64_t* n_big, orc_point* merged_out)
+{
+    if (n_frames <= 0) return 0;
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    volatile int32_t next = 0;
+    frame_job j;
+    memset(&j, 0, sizeof j);
+    j.disp = disp; j.bgr = bgr;
+    j.disp_fstride = disp_fstride; j.disp_pitch = disp_pitch; j.bgr_fstride = bgr_fstride; j.bgr_pitch = bgr_pitch;
+    j.rows = rows; j.cols = cols; j.bb = bounding_box; j.cs = cols_start_aft_cutout; j.jump = jump_pixels;
+    j.n_frames = n_frames; j.sor = sor; j.Q = Q; j.min_disp = min_disparity; j.voxel_size = voxel_size; j.poses = poses;
+    j.out = (orc_point**)calloc((size_t)n_frames, sizeof(orc_point*));
+    j.out_n = (int64_t*)calloc((size_t)n_frames, sizeof(int64_t));
+    j.next = &next;
+    if (jump_pixels > 0) {
+        const int64_t h = rows - 2 * bounding_box, w = cols - bounding_box - cols_start_aft_cutout;
+        j.cap = (h > 0 ? (h + jump_pixels - 1) / jump_pixels : 0) * (w > 0 ? (w + jump_pixels - 1) / jump_pixels : 0);
+    }
+    pthread_t th[64];
+    for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, frame_worker, &j);
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    int64_t total = 0;
+    for (int f = 0; f < n_frames; ++f) total += j.out_n[f];
+    orc_point* big = cloud_big_out ? cloud_big_out : (orc_point*)malloc((size_t)(total + 1) * sizeof(orc_point));
+    int64_t off = 0;
+    for (int f = 0; f < n_frames; ++f) {  /* frame order, pose.cpp:418-424 */
+        memcpy(big + off, j.out[f], (size_t)j.out_n[f] * sizeof(orc_point));
+        off += j.out_n[f];
+        free(j.out[f]);
+    }
+    if (n_big) *n_big = total;
+    orc_point* merged = merged_out ? merged_out : (orc_point*)malloc((size_t)(total + 1) * sizeof(orc_point));
+    const int64_t m = orc_downsample_pt_cloud(big, total, voxel_size, 1, min_points_per_voxel, ORC_ORDER_STABLE, merged, NULL);
+    if (!merged_out) free(merged);
+    if (!cloud_big_out) free(big);
+    free(j.out);
+    free(j.out_n);
     return m;
 }

@@ -70,6 +70,18 @@ int64_t orc_create_and_transform_pt_cloud(const uint8_t* disp, int64_t disp_pitc
                                           double voxel_size, int32_t dont_downsample, int32_t order,
                                           orc_point* scratch, orc_point* out, uint32_t* status);
 
+/* A7 + pose.cpp:530 as the reference runs them: A6 for n_frames frames on `threads` frame-parallel
+ * POSIX threads (pose.cpp:392-413 uses 7), results appended in frame order, then the combined merge.
+ * cloud_big_out / merged_out may be NULL (timing only).  Returns the merged count; *n_big = sum of
+ * per-frame outputs.  sor != 0 inserts the statistical outlier removal in front of every per-frame
+ * voxel grid (pose_functions.cpp:1673-1686). */
+int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_pitch, const uint8_t* bgr,
+                       int64_t bgr_fstride, int64_t bgr_pitch, int32_t rows, int32_t cols, const double Q[16],
+                       int32_t bounding_box, int32_t cols_start_aft_cutout, double min_disparity,
+                       int32_t jump_pixels, const float* poses, int32_t n_frames, double voxel_size,
+                       uint32_t min_points_per_voxel, int32_t sor, int32_t threads, orc_point* cloud_big_out,
+                       int64_t* n_big, orc_point* merged_out);
+
 /* voxel keys only (occupancy checks): writes the uint32 linear index PCL computes for each point,
  * returns 0, or ORC_STATUS_VOXEL_OVERFLOW when PCL would bail out (keys then undefined). */
 uint32_t orc_voxel_keys(const orc_point* in, int64_t n, const float leaf[3], uint32_t* keys,

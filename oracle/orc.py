@@ -48,6 +48,9 @@ def lib():
                                                         vp, i32, vp, dbl, i32, i32, vp, vp, vp]
         L.orc_statistical_outlier_removal.restype = i64
         L.orc_statistical_outlier_removal.argtypes = [vp, i64, i32, dbl, vp, vp, i32]
+        L.orc_run_frames.restype = i64
+        L.orc_run_frames.argtypes = [vp, i64, i64, vp, i64, i64, i32, i32, vp, i32, i32, dbl, i32, vp, i32, dbl, u32, i32, i32,
+                                     vp, vp, vp]
         L.orc_voxel_keys.restype = u32
         L.orc_voxel_keys.argtypes = [vp, i64, vp, vp, vp, vp]
         _lib = L
@@ -155,3 +158,27 @@ def statistical_outlier_removal(pts, mean_k=50, stddev_mul=1.0, brute=False):
     dist = np.zeros(max(len(pts), 1), np.float32)
     n = lib().orc_statistical_outlier_removal(_p(pts), len(pts), mean_k, float(stddev_mul), _p(out), _p(dist), int(bool(brute)))
     return out[:n].copy(), dist[:len(pts)]
+
+
+def run_frames(disp, bgr, Q, poses, voxel_size, jump_pixels=1, min_points_per_voxel=1, sor=False, threads=7,
+               bounding_box=20, cutout_ratio=8, min_disparity=64.0, want_clouds=True):
+    """A7 + final merge with the reference's thread fan-out, inside the C oracle (pthreads).
+    Returns (cloud_big, merged) or just the merged count when want_clouds is False (timing)."""
+    disp = np.ascontiguousarray(disp, np.uint8)
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    F, rows, cols = disp.shape
+    Q = np.ascontiguousarray(Q, np.float64).reshape(16)
+    ny, nx, cs = grid_shape(rows, cols, bounding_box, cutout_ratio, jump_pixels)
+    n_big = C.c_int64(0)
+    big = merged = None
+    if want_clouds:
+        big = np.empty(max(F * ny * nx, 1), POINT)
+        merged = np.empty(max(F * ny * nx, 1), POINT)
+    m = lib().orc_run_frames(_p(disp), disp.strides[0], disp.strides[1], _p(bgr), bgr.strides[0], bgr.strides[1], rows, cols,
+                             _p(Q), bounding_box, cs, float(min_disparity), jump_pixels, _p(poses), F, float(voxel_size),
+                             min_points_per_voxel, int(bool(sor)), threads, _p(big) if want_clouds else None,
+                             C.byref(n_big), _p(merged) if want_clouds else None)
+    if want_clouds:
+        return big[: n_big.value].copy(), merged[:m].copy()
+    return m
