@@ -55,6 +55,7 @@ struct o3dr_ctx {
     double Q[16];
     bool has_Q = false;
     int max_batch = 32;
+    int scatter_ballot = 0;  // O3DR_SCATTER=ballot: the ballot-matching scatter instead of the lane-counting one
     int single_pass = 0;  // sort variant: 1 = look-back single-pass scatter, 0 = histogram/scan/scatter per pass
 
     Workspace ws;
@@ -176,6 +177,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         HIPCHK(hipMemsetAsync(w.lb_state, 0, lb_bytes, c->stream));
         w.error_flag = (uint32_t*)(c->misc_dev + 2048);
         w.single_pass = c->single_pass;
+        w.scatter_ballot = c->scatter_ballot;
         w.mm = (float*)(base + o_mm);
         w.n_valid = (uint32_t*)(base + o_nv);
         w.n_kp = (uint32_t*)(base + o_nk);
@@ -293,6 +295,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     // "lookback": single-pass chained-scan variant (correct, but measured slower than the
     // histogram/scan/scatter form on this workload: DESIGN.md section 4); default is the classic form
     c->single_pass = (sort_env && strcmp(sort_env, "lookback") == 0) ? 1 : 0;
+    const char* sc_env = getenv("O3DR_SCATTER");
+    c->scatter_ballot = (sc_env && strcmp(sc_env, "ballot") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
     if (env && atoi(env) > 0) c->max_batch = atoi(env) > 64 ? 64 : atoi(env);
     *out_ctx = c;

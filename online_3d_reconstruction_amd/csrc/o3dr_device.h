@@ -20,10 +20,10 @@ constexpr int kSortThreads = kSortWaves * kWave;
 constexpr int kSortRounds = 16;
 constexpr int kSortWaveItems = kSortRounds * kWave;
 constexpr int kSortTile = kSortWaves * kSortWaveItems;
-constexpr int kMaxRadixBits = 9;           // digits are 1..9 bits wide, chosen per frame (k_voxel_geom); measured:
+constexpr int kMaxRadixBits = 7;           // digits are 1..7 bits wide, chosen per frame (k_voxel_geom); measured:
                                           // 7-bit passes run at 3.8 TB/s, 10-bit ones at 2.5 TB/s (32-byte runs)
 constexpr int kMaxRadix = 1 << kMaxRadixBits;
-constexpr int kMaxPasses = 4;
+constexpr int kMaxPasses = 5;            // 5 x 7 bits covers a full 32-bit index
 static_assert(kMaxRadix <= 2 * kSortThreads, "k_radix_scatter handles two digits per thread");
 // generic per-point kernels
 constexpr int kPtThreads = 256;
@@ -94,6 +94,7 @@ struct Workspace {
     uint32_t* sor_n = nullptr;          // 1        inlier count
     // single-pass (look-back) sort
     int single_pass = 0;               // 1: k_voxel_keys_hist + k_radix_scatter<true>; 0: hist/scan/scatter per pass
+    int scatter_ballot = 0;            // 1: ballot-matching scatter (k_radix_scatter); 0: lane-counting (k_radix_scatter_lane)
     uint32_t* partial_hist = nullptr;  // 2048*kMaxPasses*kMaxRadix  per-workgroup digit histograms of k_voxel_keys_hist
     uint32_t* digit_start = nullptr;   // frames*kMaxPasses*kMaxRadix  exclusive digit starts per pass
     uint64_t* lb_state = nullptr;      // (sort tiles)*kMaxRadix  chained-scan words, zeroed once at allocation

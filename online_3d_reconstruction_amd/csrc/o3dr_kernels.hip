@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_voxel_geom(const float* __restrict__ mm
     g.mul2 = (uint32_t)g.div_b[0] * (uint32_t)g.div_b[1];
     if (!g.overflow) {
         // sort plan: the linear index is < div_b.x*div_b.y*div_b.z, so only that many bits are sorted,
-        // in the fewest passes of at most kMaxRadixBits bits (a wrapped 32-bit index falls back to 4 x 8)
+        // in the fewest passes of at most kMaxRadixBits bits (a wrapped 32-bit index sorts all 32 bits)
         const uint64_t cells = (uint64_t)(uint32_t)g.div_b[0] * (uint64_t)(uint32_t)g.div_b[1] * (uint64_t)(uint32_t)g.div_b[2];
         uint32_t nbits = 32;
         if (cells <= (1ull << 32)) nbits = cells > 1 ? 64u - (uint32_t)__clzll((long long)(cells - 1)) : 1u;
@@ -889,6 +889,169 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
         const int64_t i = wbase + r * kWave + lane;
         if (i < n) stage[pos[r]] = val[r];
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t p = r * kSortThreads + threadIdx.x;
+        if (p < cnt) vout[dst[r]] = stage[p];
+    }
+}
+
+// Lane-counting variant of the stable scatter (classic, per-tile histogram offsets).  A lane owns 16
+// CONSECUTIVE records, so input order = (lane, slot) order and ranking needs no cross-lane matching:
+//   A. every lane adds 1 to its own byte of cnt[digit][lane/4] (four lanes share a dword) with a
+//      returning LDS add: the old byte is the record's rank among the lane's earlier records;
+//   B. per digit row (one lane per row): running sum over the 16 dwords; each dword is repacked to
+//      [31:20] = records of lower lane-quads, [19:0] = the four lanes' counts (5 bits each);
+//   C. rank in wave = quad prefix + counts of lower lanes in the quad + own rank.
+// ~300 VALU per 1024 records instead of ~1000 for ballot matching (k_radix_scatter), which PMC showed
+// to be VALU-issue-bound.  Digits are at most 7 bits wide (kMaxRadix = 128).
+constexpr int kCntStride = 17;  // dwords per digit row: 16 lane-quads + 1 pad (conflict-free row walks)
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lane(uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
+                                                                     uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
+                                                                     int64_t cap, const VoxelGeom* __restrict__ geom, int pass,
+                                                                     int n_tiles, const uint32_t* __restrict__ hist_scanned)
+{
+    constexpr int kCntWords = kMaxRadix * kCntStride;  // per wave
+    constexpr int kRankWords = kSortWaves * kCntWords;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[kRankWords > kSortTile ? kRankWords : kSortTile];
+    __shared__ uint32_t wave_tot[kSortWaves * kMaxRadix];  // per-wave digit totals -> exclusive wave prefixes
+    __shared__ uint32_t local_base[kMaxRadix];
+    __shared__ uint32_t delta[kMaxRadix];
+    __shared__ uint32_t scan_lds[kSortWaves + 1];
+    uint32_t* stage = smem;  // overlays the counters once every record knows its position
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const VoxelGeom g = geom[f];
+    if (g.overflow || pass >= (int)g.passes) return;
+    const uint32_t n = g.n;
+    const int64_t base = (int64_t)tile * kSortTile;
+    if (base >= n) return;
+    const uint32_t cnt = (n - base < (uint32_t)kSortTile) ? (uint32_t)(n - base) : (uint32_t)kSortTile;
+    const int bpp = (int)g.bpp, bins = 1 << bpp, shift = pass * bpp;
+    const uint32_t dmask = (uint32_t)bins - 1u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t* kin = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
+    const uint32_t* vin = ((pass & 1) ? vals1 : vals0) + (int64_t)f * cap;
+    uint32_t* kout = ((pass & 1) ? keys0 : keys1) + (int64_t)f * cap;
+    uint32_t* vout = ((pass & 1) ? vals0 : vals1) + (int64_t)f * cap;
+
+    for (int i = threadIdx.x; i < kRankWords; i += kSortThreads) smem[i] = 0;
+    __syncthreads();
+
+    // ---- load: 16 consecutive records per lane (four 16-byte loads when the frame base allows it)
+    uint32_t key[kSortRounds], val[kSortRounds];
+    const int64_t lbase = base + (int64_t)w * kSortWaveItems + (int64_t)lane * kSortRounds;
+    const bool vec = ((((int64_t)f * cap) & 3) == 0) && (lbase + kSortRounds <= (int64_t)n);
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < kSortRounds / 4; ++q) {
+            const uint4 k4 = *reinterpret_cast<const uint4*>(kin + lbase + 4 * q);
+            key[4 * q] = k4.x; key[4 * q + 1] = k4.y; key[4 * q + 2] = k4.z; key[4 * q + 3] = k4.w;
+        }
+        if (pass != 0) {
+#pragma unroll
+            for (int q = 0; q < kSortRounds / 4; ++q) {
+                const uint4 v4 = *reinterpret_cast<const uint4*>(vin + lbase + 4 * q);
+                val[4 * q] = v4.x; val[4 * q + 1] = v4.y; val[4 * q + 2] = v4.z; val[4 * q + 3] = v4.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) {
+            const int64_t i = lbase + r;
+            const bool ok = i < n;
+            key[r] = ok ? kin[i] : 0xffffffffu;
+            val[r] = (pass != 0 && ok) ? vin[i] : 0u;
+        }
+    }
+    if (pass == 0) {
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) val[r] = (uint32_t)(lbase + r);
+    }
+
+    // ---- A. own-lane ranks
+    uint32_t* cw = smem + w * kCntWords;
+    const int quad = lane >> 2, sub = lane & 3;
+    uint32_t own[kSortRounds];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        own[r] = 0;
+        if (lbase + r < (int64_t)n) {
+            const uint32_t dgt = (key[r] >> shift) & dmask;
+            const uint32_t old = atomicAdd(&cw[dgt * kCntStride + quad], 1u << (8 * sub));
+            own[r] = (old >> (8 * sub)) & 255u;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- B. per digit row: quad prefixes, repack, wave total (lanes 0..63 take rows lane and lane+64)
+#pragma unroll
+    for (int h = 0; h < kMaxRadix / 64; ++h) {
+        const int row = lane + 64 * h;
+        if (row < bins) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t v = cw[row * kCntStride + j];
+                const uint32_t c0 = v & 255u, c1 = (v >> 8) & 255u, c2 = (v >> 16) & 255u, c3 = v >> 24;
+                cw[row * kCntStride + j] = (run << 20) | c0 | (c1 << 5) | (c2 << 10) | (c3 << 15);
+                run += c0 + c1 + c2 + c3;
+            }
+            wave_tot[w * kMaxRadix + row] = run;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. one digit per thread: wave prefixes, tile total, local start, global delta
+    uint32_t tot = 0;
+    const int dg = threadIdx.x;
+    if (dg < bins) {
+#pragma unroll
+        for (int ww = 0; ww < kSortWaves; ++ww) {
+            const uint32_t t = wave_tot[ww * kMaxRadix + dg];
+            wave_tot[ww * kMaxRadix + dg] = tot;
+            tot += t;
+        }
+    }
+    uint32_t tile_total;
+    const uint32_t lb = block_excl_scan_u32<kSortWaves>(tot, scan_lds, tile_total);
+    if (dg < bins) {
+        local_base[dg] = lb;
+        delta[dg] = hist_scanned[(int64_t)f * kMaxRadix * n_tiles + (int64_t)dg * n_tiles + tile] - lb;
+    }
+    __syncthreads();
+
+    // ---- C. positions inside the tile's sorted order
+    uint32_t pos[kSortRounds];
+    const uint32_t below = (1u << (5 * sub)) - 1u;  // count fields of the lower lanes of the quad
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        if (lbase + r < (int64_t)n) {
+            const uint32_t dgt = (key[r] >> shift) & dmask;
+            const uint32_t v = cw[dgt * kCntStride + quad];
+            const uint32_t lowf = v & below;
+            const uint32_t in_quad = (lowf & 31u) + ((lowf >> 5) & 31u) + ((lowf >> 10) & 31u);
+            pos[r] = local_base[dgt] + wave_tot[w * kMaxRadix + dgt] + (v >> 20) + in_quad + own[r];
+        }
+    }
+    __syncthreads();  // the staging buffer overlays the counters: everyone is done reading them
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r)
+        if (lbase + r < (int64_t)n) stage[pos[r]] = key[r];
+    __syncthreads();
+    uint32_t dst[kSortRounds];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t p = r * kSortThreads + threadIdx.x;
+        if (p < cnt) {
+            const uint32_t k = stage[p];
+            dst[r] = p + delta[(k >> shift) & dmask];
+            kout[dst[r]] = k;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r)
+        if (lbase + r < (int64_t)n) stage[pos[r]] = val[r];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
@@ -1598,9 +1761,13 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 }
                 {
                     ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
-                    k_radix_scatter<false><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                        ws.geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
-                                                                        nullptr, 0u, nullptr);
+                    if (ws.scatter_ballot)
+                        k_radix_scatter<false><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                            ws.geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
+                                                                            nullptr, 0u, nullptr);
+                    else
+                        k_radix_scatter_lane<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                          ws.geom, pass, n_sort_tiles, ws.hist);
                 }
             }
         }
