@@ -210,6 +210,12 @@ int o3dr_cloud_big_partition(o3dr_ctx* ctx, const float gmin[3], const float gma
                              int64_t* counts, uint32_t* status);
 int o3dr_finalize_global(o3dr_ctx* ctx, const float gmin[3], const float gmax[3], o3dr_point* out,
                          int64_t out_capacity, int64_t* n_out, uint32_t* status, int32_t mem);
+/* Zero-copy plumbing for step (3): *ptr = HBM address of cloud_big and its length (the send buffer; valid
+ * until the next append/partition/adopt); an HBM receive buffer for n_points points; and "the first
+ * n_points of the receive buffer are the new cloud_big" (status bits are kept). */
+int o3dr_cloud_big_view(o3dr_ctx* ctx, void** ptr, int64_t* n);
+int o3dr_cloud_big_recv_buffer(o3dr_ctx* ctx, int64_t n_points, void** ptr);
+int o3dr_cloud_big_adopt(o3dr_ctx* ctx, int64_t n_points);
 
 /* ---- measurement hooks (bench.py; not part of the reference surface) ------------------------ */
 /* kernel ids for o3dr_profile_* */

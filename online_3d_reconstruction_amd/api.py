@@ -283,6 +283,24 @@ class Context:
         Tn = self._T(T)
         L.check(self._lib.o3dr_cloud_big_transform(self._h, Tn.ctypes.data))
 
+    # zero-copy views for the multi-GPU exchange (torch tensors over the library's HBM buffers)
+    def cloudBigView(self):
+        """[n,4] int32 CUDA tensor aliasing cloud_big (no copy); valid until the cloud is modified"""
+        ptr = C.c_void_p()
+        n = C.c_int64(0)
+        L.check(self._lib.o3dr_cloud_big_view(self._h, C.byref(ptr), C.byref(n)))
+        return _device_tensor(ptr.value, n.value, self.device)
+
+    def cloudBigRecvBuffer(self, n_points):
+        """[n_points,4] int32 CUDA tensor over the library's receive buffer"""
+        ptr = C.c_void_p()
+        L.check(self._lib.o3dr_cloud_big_recv_buffer(self._h, int(n_points), C.byref(ptr)))
+        return _device_tensor(ptr.value, int(n_points), self.device)
+
+    def cloudBigAdopt(self, n_points):
+        """the first n_points of the receive buffer become cloud_big"""
+        L.check(self._lib.o3dr_cloud_big_adopt(self._h, int(n_points)))
+
     def cloudBigBBox(self):
         """(min xyz, max xyz, count) of cloud_big; (+inf, -inf, 0) when empty"""
         mn = np.empty(3, np.float32)
@@ -339,6 +357,20 @@ class Context:
         n = C.c_int64(0)
         L.check(self._lib.o3dr_profile_read(self._h, int(kernel_id), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class _DevMem:
+    """minimal __cuda_array_interface__ holder so torch can alias library-owned HBM"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def _device_tensor(ptr, n, device_index):
+    import torch
+    if n == 0 or not ptr:
+        return torch.empty((0, 4), dtype=torch.int32, device=torch.device("cuda", device_index))
+    return torch.as_tensor(_DevMem(ptr, n), device=torch.device("cuda", device_index))
 
 
 def points_from_torch(t):

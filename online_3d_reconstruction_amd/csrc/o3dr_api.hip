@@ -69,6 +69,8 @@ struct o3dr_ctx {
     // accumulating cloud (pose.cpp:434 cloud_big)
     o3dr_point* cloud_big = nullptr;
     int64_t cloud_cap = 0;
+    o3dr_point* cloud_alt = nullptr;  // second buffer: partition target / receive buffer of the exchange
+    int64_t cloud_alt_cap = 0;
     int64_t cloud_ub = 0;          // host-side upper bound of cc_big->count
     CloudCounters* cc_big = nullptr;   // device
     CloudCounters* cc_tmp = nullptr;   // device, for single-shot calls
@@ -318,6 +320,7 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     dev_release(c->st_kp);
     dev_release(c->st_poses);
     if (c->cloud_big) (void)hipFree(c->cloud_big);
+    if (c->cloud_alt) (void)hipFree(c->cloud_alt);
     if (c->cc_big) (void)hipFree(c->cc_big);
     if (c->cc_tmp) (void)hipFree(c->cc_tmp);
     if (c->cc_host) (void)hipHostFree(c->cc_host);
@@ -839,6 +842,33 @@ static int cloud_make_room(o3dr_ctx* c, int64_t extra)
     return O3DR_OK;
 }
 
+// the alternate cloud buffer with room for `need` points (contents undefined)
+static int alt_reserve(o3dr_ctx* c, int64_t need)
+{
+    if (need <= c->cloud_alt_cap) return O3DR_OK;
+    if (c->cloud_alt) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->cloud_alt));
+        c->cloud_alt = nullptr;
+        c->cloud_alt_cap = 0;
+    }
+    if (hipMalloc((void**)&c->cloud_alt, (size_t)need * sizeof(o3dr_point)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(O3DR_ERR_ALLOC, "hipMalloc failed (alternate cloud buffer)");
+    }
+    c->cloud_alt_cap = need;
+    return O3DR_OK;
+}
+static void swap_clouds(o3dr_ctx* c)
+{
+    o3dr_point* p = c->cloud_big;
+    const int64_t cap = c->cloud_cap;
+    c->cloud_big = c->cloud_alt;
+    c->cloud_cap = c->cloud_alt_cap;
+    c->cloud_alt = p;
+    c->cloud_alt_cap = cap;
+}
+
 extern "C" int o3dr_cloud_big_reserve(o3dr_ctx* c, int64_t n_points)
 {
     CTX_ENTER(c);
@@ -1083,6 +1113,46 @@ extern "C" int o3dr_finalize_global(o3dr_ctx* c, const float gmin[3], const floa
     return finalize_impl(c, gmin, gmax, out, out_capacity, n_out, status, mem);
 }
 
+// Zero-copy access for the exchange: the HBM address of cloud_big (valid until the next call that
+// appends, partitions or adopts), a receive buffer of the requested size, and "make what I received
+// the new cloud_big".
+extern "C" int o3dr_cloud_big_view(o3dr_ctx* c, void** ptr, int64_t* n)
+{
+    CTX_ENTER(c);
+    if (!ptr || !n) return fail(O3DR_ERR_INVALID_ARG, "ptr / n is NULL");
+    CloudCounters cc;
+    CHK(read_counters(c, c->cc_big, &cc));
+    c->cloud_ub = (int64_t)cc.count;
+    *ptr = c->cloud_big;
+    *n = (int64_t)cc.count;
+    return O3DR_OK;
+}
+extern "C" int o3dr_cloud_big_recv_buffer(o3dr_ctx* c, int64_t n_points, void** ptr)
+{
+    CTX_ENTER(c);
+    if (!ptr || n_points < 0) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    CHK(alt_reserve(c, n_points > 0 ? n_points : 1));
+    *ptr = c->cloud_alt;
+    return O3DR_OK;
+}
+extern "C" int o3dr_cloud_big_adopt(o3dr_ctx* c, int64_t n_points)
+{
+    CTX_ENTER(c);
+    if (n_points < 0 || n_points > c->cloud_alt_cap) return fail(O3DR_ERR_INVALID_ARG, "more points than the receive buffer holds");
+    if (n_points >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+    CloudCounters* h = c->cc_host;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    h->count = (uint64_t)n_points;
+    h->status = 0;
+    h->pad = 0;
+    // keep the status bits accumulated so far: read-modify-write of the count only
+    HIPCHK(hipMemcpyAsync(&c->cc_big->count, &h->count, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    swap_clouds(c);
+    c->cloud_ub = n_points;
+    return O3DR_OK;
+}
+
 extern "C" int o3dr_cloud_big_bbox(o3dr_ctx* c, float mn[3], float mx[3], int64_t* n_out)
 {
     CTX_ENTER(c);
@@ -1121,11 +1191,8 @@ extern "C" int o3dr_cloud_big_partition(o3dr_ctx* c, const float gmin[3], const 
     if (n == 0) return O3DR_OK;
     if (n >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
     CHK(ws_ensure(c, 1, n, false));
-    o3dr_point* nb = nullptr;
-    if (hipMalloc((void**)&nb, (size_t)c->cloud_cap * sizeof(o3dr_point)) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(O3DR_ERR_ALLOC, "hipMalloc failed (partition buffer)");
-    }
+    CHK(alt_reserve(c, n));
+    o3dr_point* nb = c->cloud_alt;
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n, 1);
     CHK(put_bbox(c, gmin, gmax));
     float leaf[3], zo;
@@ -1144,14 +1211,10 @@ extern "C" int o3dr_cloud_big_partition(o3dr_ctx* c, const float gmin[3], const 
     uint32_t* ovf_dev = (uint32_t*)(c->misc_dev + 32);
     uint64_t* cnt_dev = (uint64_t*)(c->misc_dev + 64);
     launch_partition(&c->prof, c->stream, c->ws, v, n_parts, nb, cnt_dev, ovf_dev);
-    if (hipGetLastError() != hipSuccess) {
-        (void)hipFree(nb);
-        return fail(O3DR_ERR_HIP, "partition launch failed");
-    }
+    if (hipGetLastError() != hipSuccess) return fail(O3DR_ERR_HIP, "partition launch failed");
     HIPCHK(hipMemcpyAsync(c->misc_host, c->misc_dev, 64 + 8 * (size_t)n_parts, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(c->cloud_big));
-    c->cloud_big = nb;
+    swap_clouds(c);  // the partitioned copy becomes cloud_big; the old buffer is kept as the alternate
     const uint32_t ovf = *(const uint32_t*)(c->misc_host + 32);
     const uint64_t* hc = (const uint64_t*)(c->misc_host + 64);
     for (int p = 0; p < n_parts; ++p) counts[p] = (int64_t)hc[p];

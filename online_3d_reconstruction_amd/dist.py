@@ -93,11 +93,25 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
     if status & 1:  # PCL's overflow guard on the global box: the merge returns its input unchanged
         counts = [0] * world
         counts[rank] = n_local  # everything stays where it is; rank order is already global order
-    send = ctx.cloudBigRead(device=device).to(cdev)
-    recv, _ = _all_to_all_points(send, counts, group)
-    ctx.cloudBigReset()
-    if recv.shape[0]:
-        ctx.cloudBigAppend(recv.to(device))
+    zero_copy = comm_device is None and hasattr(ctx, "cloudBigView") and str(device).startswith("cuda")
+    if zero_copy:
+        # send straight out of cloud_big, receive straight into the library's second cloud buffer
+        send = ctx.cloudBigView()
+        sc = torch.tensor(counts, dtype=torch.int64, device=device)
+        rc = torch.empty(world, dtype=torch.int64, device=device)
+        dist.all_to_all_single(rc, sc, group=group)
+        recv_counts = [int(v) for v in rc.tolist()]
+        n_recv = sum(recv_counts)
+        recv = ctx.cloudBigRecvBuffer(n_recv)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
+        torch.cuda.current_stream(device).synchronize()
+        ctx.cloudBigAdopt(n_recv)
+    else:
+        send = ctx.cloudBigRead(device=device).to(cdev)
+        recv, _ = _all_to_all_points(send, counts, group)
+        ctx.cloudBigReset()
+        if recv.shape[0]:
+            ctx.cloudBigAppend(recv.to(device))
     mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax)
     if not gather_result:
         return mine, total
