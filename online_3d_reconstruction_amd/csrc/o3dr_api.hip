@@ -54,6 +54,8 @@ struct o3dr_ctx {
     o3dr_params params;
     double Q[16];
     bool has_Q = false;
+    QLutEntry* q_lut = nullptr;  // device table for rectified-stereo Q (nullptr: general 4x4 product per pixel)
+    bool q_lut_on = false;
     int max_batch = 32;
     int scatter_ballot = 0;  // O3DR_SCATTER=ballot: the ballot-matching scatter instead of the lane-counting one
     int single_pass = 0;  // sort variant: 1 = look-back single-pass scatter, 0 = histogram/scan/scatter per pass
@@ -78,6 +80,7 @@ struct o3dr_ctx {
     uint32_t* n_host = nullptr;        // pinned scratch (4 words)
     uint8_t* misc_dev = nullptr;       // 4 KiB device scratch: bbox (6 f32) | overflow (u32) | part counts (256 u64)
     uint8_t* misc_host = nullptr;      // pinned mirror
+    uint8_t* misc_host_lut = nullptr;  // pinned staging of the Q table
     SortStats* stats_dev = nullptr;    // device statistics (bench.py byte accounting)
     SortStats* stats_host = nullptr;   // pinned
 
@@ -285,6 +288,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
         hipMalloc((void**)&c->stats_dev, sizeof(SortStats)) != hipSuccess ||
         hipMalloc((void**)&c->misc_dev, 4096) != hipSuccess ||
         hipHostMalloc((void**)&c->misc_host, 4096, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->misc_host_lut, 256 * sizeof(QLutEntry), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&c->q_lut, 256 * sizeof(QLutEntry)) != hipSuccess ||
         hipHostMalloc((void**)&c->stats_host, sizeof(SortStats), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(O3DR_ERR_ALLOC, "counter allocation failed");
@@ -328,6 +333,8 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->stats_dev) (void)hipFree(c->stats_dev);
     if (c->misc_dev) (void)hipFree(c->misc_dev);
     if (c->misc_host) (void)hipHostFree(c->misc_host);
+    if (c->misc_host_lut) (void)hipHostFree(c->misc_host_lut);
+    if (c->q_lut) (void)hipFree(c->q_lut);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -359,6 +366,28 @@ extern "C" int o3dr_set_camera(o3dr_ctx* c, const double Q[16])
     if (!Q) return fail(O3DR_ERR_INVALID_ARG, "Q is NULL");
     memcpy(c->Q, Q, sizeof c->Q);
     c->has_Q = true;
+    // Rectified stereo Q (cv::stereoRectify): X and Y rows use one pixel coordinate each, Z and W only the
+    // disparity.  Then 1./W and Z are functions of the 8-bit disparity alone: tabulate them with the very
+    // operations the per-pixel path would execute (IEEE fp64 on both sides), drop the exact-zero terms.
+    static const int zeros[] = {1, 2, 4, 6, 8, 9, 12, 13};
+    bool sparse = true;
+    for (int z : zeros) sparse = sparse && (Q[z] == 0.0);
+    c->q_lut_on = false;
+    if (sparse) {
+        QLutEntry* h = (QLutEntry*)c->misc_host_lut;
+        for (int d = 0; d < 256; ++d) {
+            const double dd = (double)d;
+            const double t2 = ((Q[8] * 0.0 + Q[9] * 0.0) + Q[10] * dd) + Q[11];
+            const double t3 = ((Q[12] * 0.0 + Q[13] * 0.0) + Q[14] * dd) + Q[15];
+            const double alpha = 1. / t3;
+            h[d].alpha = alpha;
+            h[d].z = (float)(t2 * alpha + 0.0);
+            h[d].pad = 0.f;
+        }
+        HIPCHK(hipMemcpyAsync(c->q_lut, h, 256 * sizeof(QLutEntry), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->q_lut_on = getenv("O3DR_NO_QLUT") == nullptr;
+    }
     return O3DR_OK;
 }
 extern "C" int o3dr_set_params(o3dr_ctx* c, const o3dr_params* p)
@@ -443,6 +472,7 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
     a.min_disp = c->params.min_disparity;
     a.out_fstride = out_fstride;
     a.mm_stride = c->ws.mm_stride;
+    a.lut = c->q_lut_on ? c->q_lut : nullptr;
 }
 
 // stage a host buffer into HBM (or pass a device pointer through)

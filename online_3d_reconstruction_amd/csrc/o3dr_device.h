@@ -51,6 +51,12 @@ struct SorGeom {
     double threshold;
 };
 
+// disparity-byte table of the rectified-stereo fast path: alpha = 1./(Q[14]*d + Q[15]), z = float(t2*alpha + 0)
+struct QLutEntry {
+    double alpha;
+    float z, pad;
+};
+
 // ---- arguments of the fused reprojection kernels (A1 + A2) ------------------------------------
 struct ReprojectArgs {
     const uint8_t* disp;  // frame f at disp + f*disp_fstride
@@ -67,6 +73,7 @@ struct ReprojectArgs {
     double min_disp;
     int64_t out_fstride;  // points between consecutive frames' output regions
     int64_t mm_stride;    // bounding-box slots per frame
+    const QLutEntry* lut; // 256 entries in HBM when Q has the rectified-stereo sparsity, else nullptr
 };
 
 // All per-batch device buffers.  Sizes are for `frames` frames of at most `cap` points each.

@@ -200,6 +200,13 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
     __shared__ uint4 stage[kEmitTile];  // 16 KiB: the tile's points in output order
     __shared__ uint32_t scan_lds[kEmitThreads / 64 + 1];
     __shared__ float mm_lds[6 * (kEmitThreads / 64)];
+    __shared__ double lut_alpha[256];  // rectified-stereo Q: 1/w and Z depend on the disparity byte only
+    __shared__ float lut_z[256];
+    if (a.lut) {
+        lut_alpha[threadIdx.x] = a.lut[threadIdx.x].alpha;
+        lut_z[threadIdx.x] = a.lut[threadIdx.x].z;
+        __syncthreads();
+    }
     const int f = blockIdx.y, tile = blockIdx.x;
     const uint8_t* disp = a.disp + (int64_t)f * a.disp_fstride;
     const uint8_t* bgr = a.bgr + (int64_t)f * a.bgr_fstride;
@@ -251,7 +258,24 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
                     cg[k] = px[1];
                     cr[k] = px[2];
                 }
-                p[k] = reproject_one(a.Q, x, y, (double)d[k], cb[k], cg[k], cr[k], m, xf);
+                if (a.lut) {
+                    // same arithmetic as reproject_one with the exact-zero terms of Q dropped (adding
+                    // +-0 and multiplying by the tabulated 1./w change no bit of the result)
+                    const double al = lut_alpha[d[k]];
+                    const float X = (float)((a.Q[0] * (double)x + a.Q[3]) * al + 0.0);
+                    const float Y = (float)((a.Q[5] * (double)y + a.Q[7]) * al + 0.0);
+                    const float Z = lut_z[d[k]];
+                    if (xf) {
+                        p[k].x = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+                        p[k].y = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+                        p[k].z = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+                    } else {
+                        p[k].x = X; p[k].y = Y; p[k].z = Z;
+                    }
+                    p[k].rgba = (cr[k] << 16) | (cg[k] << 8) | cb[k];
+                } else {
+                    p[k] = reproject_one(a.Q, x, y, (double)d[k], cb[k], cg[k], cr[k], m, xf);
+                }
                 lo[0] = fminf(lo[0], p[k].x); hi[0] = fmaxf(hi[0], p[k].x);
                 lo[1] = fminf(lo[1], p[k].y); hi[1] = fmaxf(hi[1], p[k].y);
                 lo[2] = fminf(lo[2], p[k].z); hi[2] = fmaxf(hi[2], p[k].z);
@@ -1624,7 +1648,7 @@ static void launch_scan(hipStream_t s, uint32_t* data, int64_t L, int64_t row_st
                         const uint32_t* add, uint32_t* partial, const VoxelGeom* geom = nullptr, int pass = 0,
                         int n_tiles = 0)
 {
-    if (L <= 2 * kScanChunk) {
+    if (L <= 4 * kScanChunk) {  // one 1024-thread workgroup per row is faster than three launches up to ~16k words
         k_scan_rows<<<frames, 1024, 0, s>>>(data, L, row_stride, totals, add, geom, pass, n_tiles, 0);
         return;
     }
