@@ -56,7 +56,7 @@ struct o3dr_ctx {
     bool has_Q = false;
     QLutEntry* q_lut = nullptr;  // device table for rectified-stereo Q (nullptr: general 4x4 product per pixel)
     bool q_lut_on = false;
-    int max_batch = 32;
+    int max_batch = 256;  // frames per launch group (O3DR_BATCH_FRAMES); also bounded by a workspace budget
     int scatter_ballot = 0;  // O3DR_SCATTER=ballot: the ballot-matching scatter instead of the lane-counting one
     int single_pass = 0;  // sort variant: 1 = look-back single-pass scatter, 0 = histogram/scan/scatter per pass
 
@@ -305,7 +305,7 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     const char* sc_env = getenv("O3DR_SCATTER");
     c->scatter_ballot = (sc_env && strcmp(sc_env, "ballot") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
-    if (env && atoi(env) > 0) c->max_batch = atoi(env) > 64 ? 64 : atoi(env);
+    if (env && atoi(env) > 0) c->max_batch = atoi(env) > 512 ? 512 : atoi(env);
     *out_ctx = c;
     return O3DR_OK;
 }
@@ -1040,7 +1040,12 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         }
         return O3DR_OK;
     }
-    const int B = n_frames < c->max_batch ? n_frames : c->max_batch;
+    int B = n_frames < c->max_batch ? n_frames : c->max_batch;
+    {   // ~56 bytes of workspace per candidate point; keep a batch under 12 GiB of HBM (of 288)
+        const int64_t per_frame = 56 * g.n + (1 << 20);
+        const int64_t fit = ((int64_t)12 << 30) / per_frame;
+        if (fit < B) B = fit < 1 ? 1 : (int)fit;
+    }
     CHK(ws_ensure(c, B, g.n, true));
 
     for (int f0 = 0; f0 < n_frames; f0 += B) {

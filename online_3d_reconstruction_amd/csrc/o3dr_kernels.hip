@@ -1196,39 +1196,53 @@ __global__ __launch_bounds__(256) void k_keep_write(const uint32_t* __restrict__
     }
 }
 
-// per-frame output counts -> absolute offsets; advances the cloud counter (one thread: frames <= 64)
-__global__ void k_frame_offsets(const VoxelGeom* __restrict__ geom, const uint32_t* __restrict__ n_vox,
-                                const uint32_t* __restrict__ n_keep, int frames, int passthrough,
-                                uint32_t* __restrict__ n_out, uint64_t* __restrict__ out_off,
-                                CloudCounters* __restrict__ cc, SortStats* __restrict__ stats)
+// per-frame output counts -> absolute offsets; advances the cloud counter (one 256-thread workgroup,
+// frames in chunks of 256; a batch's total stays far below 2^32 points)
+__global__ __launch_bounds__(256) void k_frame_offsets(const VoxelGeom* __restrict__ geom, const uint32_t* __restrict__ n_vox,
+                                                       const uint32_t* __restrict__ n_keep, int frames, int passthrough,
+                                                       uint32_t* __restrict__ n_out, uint64_t* __restrict__ out_off,
+                                                       CloudCounters* __restrict__ cc, SortStats* __restrict__ stats)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint64_t run = cc->count;
-    uint32_t st = 0;
-    uint64_t rec_passes = 0, pts = 0, outs = 0;
-    for (int f = 0; f < frames; ++f) {
-        uint32_t m;
-        if (passthrough) {
-            m = geom[f].n;
-        } else if (geom[f].overflow) {
-            m = geom[f].n;
-            st |= O3DR_STATUS_VOXEL_OVERFLOW;
-        } else {
-            m = n_keep ? n_keep[f] : n_vox[f];
-            rec_passes += (uint64_t)geom[f].n * geom[f].passes;
-            pts += geom[f].n;
-            outs += m;
+    __shared__ uint32_t scan_lds[5];
+    __shared__ unsigned long long acc[4];  // record-passes, points in, points out, status
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = cc->count;
+    uint64_t carry = 0;
+    for (int f0 = 0; f0 < frames; f0 += 256) {
+        const int f = f0 + threadIdx.x;
+        uint32_t m = 0;
+        if (f < frames) {
+            const VoxelGeom g = geom[f];
+            if (passthrough) {
+                m = g.n;
+            } else if (g.overflow) {
+                m = g.n;
+                atomicOr(&acc[3], (unsigned long long)O3DR_STATUS_VOXEL_OVERFLOW);
+            } else {
+                m = n_keep ? n_keep[f] : n_vox[f];
+                atomicAdd(&acc[0], (unsigned long long)g.n * g.passes);
+                atomicAdd(&acc[1], (unsigned long long)g.n);
+                atomicAdd(&acc[2], (unsigned long long)m);
+            }
         }
-        n_out[f] = m;
-        out_off[f] = run;
-        run += m;
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_u32<4>(m, scan_lds, total);
+        if (f < frames) {
+            n_out[f] = m;
+            out_off[f] = base + carry + excl;
+        }
+        carry += total;
     }
-    cc->count = run;
-    cc->status |= st;
-    if (stats) {
-        stats->sort_record_passes += rec_passes;
-        stats->voxel_points_in += pts;
-        stats->voxel_points_out += outs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cc->count = base + carry;
+        cc->status |= (uint32_t)acc[3];
+        if (stats) {
+            stats->sort_record_passes += acc[0];
+            stats->voxel_points_in += acc[1];
+            stats->voxel_points_out += acc[2];
+        }
     }
 }
 
@@ -1829,8 +1843,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     }
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
-        k_frame_offsets<<<1, 1, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc,
-                                        v.stats);
+        k_frame_offsets<<<1, 256, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc,
+                                          v.stats);
     }
     if (cap > 0) {
         ProfScope ps(pf, O3DR_K_CENTROID, s);
