@@ -702,17 +702,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
                                                              const VoxelGeom* __restrict__ geom, int pass,
                                                              int n_tiles, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t h[kMaxRadix];
+    __shared__ uint32_t h[kSortWaves * kMaxRadix];  // one private table per wave: no cross-wave contention
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom[f];
     if (g.overflow || pass >= (int)g.passes) return;
     const uint32_t n = g.n;
     const int bins = 1 << g.bpp, shift = pass * (int)g.bpp;
     const uint32_t dmask = (uint32_t)bins - 1u;
-    for (int i = threadIdx.x; i < bins; i += kSortThreads) h[i] = 0;
+    for (int i = threadIdx.x; i < kSortWaves * kMaxRadix; i += kSortThreads) h[i] = 0;
     __syncthreads();
     const uint32_t* src = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
     const int64_t base = (int64_t)tile * kSortTile;
+    uint32_t* hw = h + (threadIdx.x >> 6) * kMaxRadix;
     if (base < n) {
         // a histogram does not care which lane sees which record: 16-byte loads, 4 per lane
         const bool vec = (((int64_t)f * cap) & 3) == 0;  // tile bases are multiples of 8192
@@ -721,19 +722,24 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
             const int64_t i = base + ((int64_t)r * kSortThreads + threadIdx.x) * 4;
             if (vec && i + 3 < n) {
                 const uint4 v = *reinterpret_cast<const uint4*>(src + i);
-                atomicAdd(&h[(v.x >> shift) & dmask], 1u);
-                atomicAdd(&h[(v.y >> shift) & dmask], 1u);
-                atomicAdd(&h[(v.z >> shift) & dmask], 1u);
-                atomicAdd(&h[(v.w >> shift) & dmask], 1u);
+                atomicAdd(&hw[(v.x >> shift) & dmask], 1u);
+                atomicAdd(&hw[(v.y >> shift) & dmask], 1u);
+                atomicAdd(&hw[(v.z >> shift) & dmask], 1u);
+                atomicAdd(&hw[(v.w >> shift) & dmask], 1u);
             } else {
                 for (int k = 0; k < 4; ++k)
-                    if (i + k < n) atomicAdd(&h[(src[i + k] >> shift) & dmask], 1u);
+                    if (i + k < n) atomicAdd(&hw[(src[i + k] >> shift) & dmask], 1u);
             }
         }
     }
     __syncthreads();
     uint32_t* dst = hist + (int64_t)f * kMaxRadix * n_tiles;
-    for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) dst[(int64_t)dgt * n_tiles + tile] = h[dgt];
+    for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int ww = 0; ww < kSortWaves; ++ww) t += h[ww * kMaxRadix + dgt];
+        dst[(int64_t)dgt * n_tiles + tile] = t;
+    }
 }
 
 // Chained-scan ("look-back") state of the single-pass variant: one 64-bit word per (tile, digit),
