@@ -85,6 +85,11 @@ struct o3dr_ctx {
     SortStats* stats_host = nullptr;   // pinned
 
     DevBuf st_disp, st_bgr, st_in, st_out, st_kp, st_poses;
+    // host-input streaming of o3dr_accumulate_frames: two staging sets, uploads on their own stream
+    DevBuf st2_disp[2], st2_bgr[2], st2_poses[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int host_batch = 32;  // frames per upload while the previous batch computes (O3DR_HOST_BATCH_FRAMES)
     Profiler prof;
 };
 
@@ -302,6 +307,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     // "lookback": single-pass chained-scan variant (correct, but measured slower than the
     // histogram/scan/scatter form on this workload: DESIGN.md section 4); default is the classic form
     c->single_pass = (sort_env && strcmp(sort_env, "lookback") == 0) ? 1 : 0;
+    const char* hb_env = getenv("O3DR_HOST_BATCH_FRAMES");
+    if (hb_env && atoi(hb_env) > 0) c->host_batch = atoi(hb_env);
     const char* sc_env = getenv("O3DR_SCATTER");
     c->scatter_ballot = (sc_env && strcmp(sc_env, "ballot") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
@@ -336,6 +343,14 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->misc_host_lut) (void)hipHostFree(c->misc_host_lut);
     if (c->q_lut) (void)hipFree(c->q_lut);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
+    for (int i = 0; i < 2; ++i) {
+        dev_release(c->st2_disp[i]);
+        dev_release(c->st2_bgr[i]);
+        dev_release(c->st2_poses[i]);
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return O3DR_OK;
@@ -1048,13 +1063,42 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
     }
     CHK(ws_ensure(c, B, g.n, true));
 
-    for (int f0 = 0; f0 < n_frames; f0 += B) {
+    const bool streaming = mem == O3DR_MEM_HOST;
+    if (streaming) {
+        // Host buffers: frames cross PCIe once.  Upload batch k+1 on a second stream while batch k
+        // computes (two staging sets); smaller batches than the HBM-resident path so that they overlap.
+        if (c->host_batch < B) B = c->host_batch;
+        if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            if (!c->ev_copied[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+            if (!c->ev_done[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));  // staging sets are free, events start clean
+    }
+    int slot = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += B, slot ^= 1) {
         const int nb = (n_frames - f0) < B ? (n_frames - f0) : B;
         CHK(cloud_make_room(c, (int64_t)nb * g.n));
         const void *disp_d, *bgr_d, *poses_d;
-        CHK(stage_in(c, c->st_disp, disp + (int64_t)f0 * disp_frame_stride, (size_t)nb * disp_frame_stride, mem, &disp_d));
-        CHK(stage_in(c, c->st_bgr, bgr + (int64_t)f0 * bgr_frame_stride, (size_t)nb * bgr_frame_stride, mem, &bgr_d));
-        CHK(stage_in(c, c->st_poses, poses + 16 * (int64_t)f0, (size_t)nb * 16 * sizeof(float), mem, &poses_d));
+        if (streaming) {
+            const size_t db = (size_t)nb * disp_frame_stride, cb = (size_t)nb * bgr_frame_stride, pb = (size_t)nb * 16 * sizeof(float);
+            CHK(dev_ensure(c, c->st2_disp[slot], db));
+            CHK(dev_ensure(c, c->st2_bgr[slot], cb));
+            CHK(dev_ensure(c, c->st2_poses[slot], pb));
+            if (f0 >= 2 * B) HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[slot], 0));  // set's previous user finished
+            HIPCHK(hipMemcpyAsync(c->st2_disp[slot].p, disp + (int64_t)f0 * disp_frame_stride, db, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(hipMemcpyAsync(c->st2_bgr[slot].p, bgr + (int64_t)f0 * bgr_frame_stride, cb, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(hipMemcpyAsync(c->st2_poses[slot].p, poses + 16 * (int64_t)f0, pb, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(hipEventRecord(c->ev_copied[slot], c->copy_stream));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[slot], 0));
+            disp_d = c->st2_disp[slot].p;
+            bgr_d = c->st2_bgr[slot].p;
+            poses_d = c->st2_poses[slot].p;
+        } else {
+            disp_d = disp + (int64_t)f0 * disp_frame_stride;
+            bgr_d = bgr + (int64_t)f0 * bgr_frame_stride;
+            poses_d = poses + 16 * (int64_t)f0;
+        }
         ReprojectArgs a;
         fill_args(c, a, (const uint8_t*)disp_d, disp_pitch, disp_frame_stride, (const uint8_t*)bgr_d, bgr_pitch,
                   bgr_frame_stride, rows, cols, g, g.n);
@@ -1082,8 +1126,9 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         c->cloud_ub += (int64_t)nb * g.n;
-        if (mem == O3DR_MEM_HOST) HIPCHK(hipStreamSynchronize(c->stream));  // staging buffers are reused
+        if (streaming) HIPCHK(hipEventRecord(c->ev_done[slot], c->stream));
     }
+    if (streaming) HIPCHK(hipStreamSynchronize(c->stream));  // the caller may reuse its host buffers
     return O3DR_OK;
 }
 

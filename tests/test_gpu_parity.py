@@ -464,3 +464,21 @@ def test_zero_copy_exchange_single_rank_rccl(orc):
             assert c.cloudBigSize()[0] == total
     finally:
         dist.destroy_process_group()
+
+
+def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
+    """host buffers, upload batches of 2 frames double-buffered against compute: same cloud as one batch"""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    monkeypatch.setenv("O3DR_HOST_BATCH_FRAMES", "2")
+    Qs = synth.camera_Q()
+    F = 9
+    disp, bgr = synth.make_frames(60, F, invalid_frac=0.01)
+    poses = synth.make_poses(60, F)
+    with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=3, voxel_size=0.05)) as c:
+        c.accumulateFrames(disp, bgr, poses)
+        big = c.cloudBigRead()
+        small = c.finalize()
+    rbig, rsmall, _ = _oracle_run(orc, Qs, disp, bgr, poses, 0.05, 3, 1)
+    assert_points_equal(big, rbig, "cloud_big (streamed host input)")
+    assert_points_equal(small, rsmall, "cloud_small (streamed host input)")
