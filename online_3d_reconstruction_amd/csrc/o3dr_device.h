@@ -14,14 +14,15 @@ constexpr int kWave = 64;
 constexpr int kEmitThreads = 256;
 constexpr int kEmitPerLane = 4;
 constexpr int kEmitTile = kEmitThreads * kEmitPerLane;
-// radix sort: 8 waves x 16 rounds x 64 lanes = 8192 keys per workgroup, 8-bit digits
+// radix sort: 8 waves x 16 records per lane x 64 lanes = 8192 records per workgroup
 constexpr int kSortWaves = 8;
 constexpr int kSortThreads = kSortWaves * kWave;
 constexpr int kSortRounds = 16;
 constexpr int kSortWaveItems = kSortRounds * kWave;
 constexpr int kSortTile = kSortWaves * kSortWaveItems;
-constexpr int kMaxRadixBits = 7;           // digits are 1..7 bits wide, chosen per frame (k_voxel_geom); measured:
-                                          // 7-bit passes run at 3.8 TB/s, 10-bit ones at 2.5 TB/s (32-byte runs)
+constexpr int kMaxRadixBits = 7;           // digits are 1..7 bits wide, chosen per frame (k_voxel_geom).  Measured with
+                                          // the ballot scatter: 7-bit passes 3.8 TB/s, 10-bit ones 2.5 TB/s (32-byte
+                                          // output runs); the lane-counting scatter keeps 128 x 17 counters per wave
 constexpr int kMaxRadix = 1 << kMaxRadixBits;
 constexpr int kMaxPasses = 5;            // 5 x 7 bits covers a full 32-bit index
 static_assert(kMaxRadix <= 2 * kSortThreads, "k_radix_scatter handles two digits per thread");
