@@ -1511,24 +1511,49 @@ __global__ __launch_bounds__(256) void k_sor_cell_table(const o3dr_point* __rest
 }
 
 constexpr int kSorThreads = 128;
+// The 51 smallest squared distances of a query live in a binary MAX-heap, one LDS column per lane
+// (conflict-free): a candidate below the current maximum replaces the root and sifts down (<= 6 levels)
+// instead of shifting an ordered list.  At the end the heap is sorted in place (heap sort), because the
+// reference adds the distances in ascending order and the fp64 sum is order sensitive in its last bits.
+__device__ __forceinline__ void sor_sift_down(float (*heap)[kSorThreads], int t, int n, int i, float v)
+{
+    for (;;) {
+        int c = 2 * i + 1;
+        if (c >= n) break;
+        float cv = heap[c][t];
+        if (c + 1 < n) {
+            const float rv = heap[c + 1][t];
+            if (rv > cv) {
+                cv = rv;
+                ++c;
+            }
+        }
+        if (!(cv > v)) break;
+        heap[i][t] = cv;
+        i = c;
+    }
+    heap[i][t] = v;
+}
+
 __global__ __launch_bounds__(kSorThreads) void k_sor_knn(const o3dr_point* __restrict__ in, const float4* __restrict__ sxyz,
                                                          const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ cell_end,
                                                          const SorGeom* __restrict__ sg, float* __restrict__ dist)
 {
-    __shared__ float best[kSorMeanK + 1][kSorThreads];  // column per lane: conflict-free
+    constexpr int K = kSorMeanK + 1;
+    __shared__ float heap[K][kSorThreads];
     const SorGeom g = *sg;
     if (!g.active) return;
     const int64_t i = (int64_t)blockIdx.x * kSorThreads + threadIdx.x;
     if (i >= g.n) return;
     const int t = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k <= kSorMeanK; ++k) best[k][t] = __builtin_huge_valf();
+    for (int k = 0; k < K; ++k) heap[k][t] = __builtin_huge_valf();  // all-equal values form a valid heap
     const uint4 qv = reinterpret_cast<const uint4*>(in)[i];
     const float qx = __uint_as_float(qv.x), qy = __uint_as_float(qv.y), qz = __uint_as_float(qv.z);
     int cx, cy;
     sor_cell(g, qx, qy, cx, cy);
-    float worst = __builtin_huge_valf();
+    float worst = __builtin_huge_valf();  // heap root = 51st smallest so far
     const int rmax = g.gx > g.gy ? g.gx : g.gy;
     for (int r = 0; r <= rmax; ++r) {
         for (int yy = cy - r; yy <= cy + r; ++yy) {
@@ -1543,16 +1568,9 @@ __global__ __launch_bounds__(kSorThreads) void k_sor_knn(const o3dr_point* __res
                     const float4 p = sxyz[sidx];
                     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
                     const float d = ((0.0f + dx * dx) + dy * dy) + dz * dz;
-                    if (d < worst) {  // insert into the ascending list
-                        int j = kSorMeanK;
-                        while (j > 0) {
-                            const float b = best[j - 1][t];
-                            if (!(b > d)) break;
-                            best[j][t] = b;
-                            --j;
-                        }
-                        best[j][t] = d;
-                        worst = best[kSorMeanK][t];
+                    if (d < worst) {  // replaces the current maximum
+                        sor_sift_down(heap, t, K, 0, d);
+                        worst = heap[0][t];
                     }
                 }
             }
@@ -1560,8 +1578,15 @@ __global__ __launch_bounds__(kSorThreads) void k_sor_knn(const o3dr_point* __res
         const double bound = 0.999 * (double)r * (double)g.h;
         if (worst < __builtin_huge_valf() && (double)worst <= bound * bound) break;
     }
+    // heap sort: ascending order in place
+    for (int n = K - 1; n > 0; --n) {
+        const float top = heap[0][t];
+        const float last = heap[n][t];
+        heap[n][t] = top;
+        sor_sift_down(heap, t, n, 0, last);
+    }
     double dist_sum = 0.0;
-    for (int k = 1; k <= kSorMeanK; ++k) dist_sum += sqrt((double)best[k][t]);
+    for (int k = 1; k < K; ++k) dist_sum += sqrt((double)heap[k][t]);
     dist[i] = (float)(dist_sum / (double)kSorMeanK);
 }
 
