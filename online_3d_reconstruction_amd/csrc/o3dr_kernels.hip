@@ -1535,7 +1535,12 @@ __device__ __forceinline__ void sor_sift_down(float (*heap)[kSorThreads], int t,
     heap[i][t] = v;
 }
 
-__global__ __launch_bounds__(kSorThreads) void k_sor_knn(const o3dr_point* __restrict__ in, const float4* __restrict__ sxyz,
+// Queries are taken in CELL order (thread j = j-th point of the cell-sorted array): the lanes of a wave sit
+// in the same or adjacent columns, walk the same rings and read the same candidates (one broadcast load
+// per candidate instead of 64 scattered ones); the result goes back to the point's original index.
+__global__ __launch_bounds__(kSorThreads) void k_sor_knn(const float4* __restrict__ sxyz, const uint32_t* __restrict__ ids0,
+                                                         const uint32_t* __restrict__ ids1,
+                                                         const VoxelGeom* __restrict__ geom,
                                                          const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ cell_end,
                                                          const SorGeom* __restrict__ sg, float* __restrict__ dist)
@@ -1549,8 +1554,9 @@ __global__ __launch_bounds__(kSorThreads) void k_sor_knn(const o3dr_point* __res
     const int t = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < K; ++k) heap[k][t] = __builtin_huge_valf();  // all-equal values form a valid heap
-    const uint4 qv = reinterpret_cast<const uint4*>(in)[i];
-    const float qx = __uint_as_float(qv.x), qy = __uint_as_float(qv.y), qz = __uint_as_float(qv.z);
+    const float4 qv = sxyz[i];
+    const float qx = qv.x, qy = qv.y, qz = qv.z;
+    const uint32_t out_index = ((geom[0].passes & 1u) ? ids1 : ids0)[i];
     int cx, cy;
     sor_cell(g, qx, qy, cx, cy);
     float worst = __builtin_huge_valf();  // heap root = 51st smallest so far
@@ -1587,7 +1593,7 @@ __global__ __launch_bounds__(kSorThreads) void k_sor_knn(const o3dr_point* __res
     }
     double dist_sum = 0.0;
     for (int k = 1; k < K; ++k) dist_sum += sqrt((double)heap[k][t]);
-    dist[i] = (float)(dist_sum / (double)kSorMeanK);
+    dist[out_index] = (float)(dist_sum / (double)kSorMeanK);
 }
 
 // sum and sum of squares (float product like PCL, fp64 sums): fixed-shape two-level reduction
@@ -1938,8 +1944,8 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     }
     k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
                                                      ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);
-    k_sor_knn<<<cdiv64(cap, kSorThreads), kSorThreads, 0, s>>>(in, ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end, ws.sor_geom,
-                                                              ws.sor_dist);
+    k_sor_knn<<<cdiv64(cap, kSorThreads), kSorThreads, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_start,
+                                                              ws.sor_cell_end, ws.sor_geom, ws.sor_dist);
     constexpr int kStatBlocks = 256;
     k_sor_partial<<<kStatBlocks, 256, 0, s>>>(ws.sor_dist, ws.sor_geom, ws.sor_partial);
     k_sor_threshold<<<1, 1, 0, s>>>(ws.sor_partial, kStatBlocks, stddev_mul, ws.sor_geom);
