@@ -6,7 +6,7 @@ streaming reads (verified here: k_voxel_keys reads exactly 16 B/point and FETCH_
 of that; k_radix_hist reads 4 B/record, ratio 0.500), WRITE_SIZE is exact for streaming stores
 (k_reproject_emit: 16 B/point, ratio 1.00).  Counter unit is KiB.
 
-    python profiles/make_pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+    python profiles/make_pmc_traffic.py gpurun_out/r01_fetch gpurun_out/r01_write profiles/r01_pmc_traffic.json
 """
 import collections
 import csv
@@ -27,7 +27,8 @@ def load(d, counter):
 
 def main():
     fetch_dir, write_dir, out_path = sys.argv[1:4]
-    dominant = sys.argv[4] if len(sys.argv) > 4 else "radix_scatter"
+    dominant = sys.argv[4] if len(sys.argv) > 4 else "radix_scatter_lane"  # kernel symbol (without o3dr::k_)
+    bench_class = sys.argv[5] if len(sys.argv) > 5 else "radix_scatter"   # bench.py's kernel class name
     f, w = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(f) | set(w)):
@@ -36,7 +37,8 @@ def main():
         write = sum(w.get(k, [])) * 1024.0
         kernels[k] = {"launches": n, "fetch_bytes_per_launch": round(fetch / n), "write_bytes_per_launch": round(write / n),
                       "hbm_bytes_per_launch": round((fetch + write) / n)}
-    doc = {"kernel": dominant, "hbm_bytes_per_launch": kernels.get(dominant, {}).get("hbm_bytes_per_launch"),
+    doc = {"kernel": bench_class, "kernel_symbol": "o3dr::k_" + dominant,
+           "hbm_bytes_per_launch": kernels.get(dominant, {}).get("hbm_bytes_per_launch"),
            "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes", "kernels": kernels}
     json.dump(doc, open(out_path, "w"), indent=1)
     print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in kernels.items()}))
