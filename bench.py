@@ -169,7 +169,7 @@ def main():
     step()
     per_kernel = {L.KERNEL_NAMES[k]: ctx.profileRead(k) for k in range(len(L.KERNEL_NAMES))}
     ctx.profileEnable(-1, False)
-    dom = max(range(len(L.KERNEL_NAMES) - 1), key=lambda k: per_kernel[L.KERNEL_NAMES[k]][0])
+    dom = max((k for k in range(len(L.KERNEL_NAMES)) if k != L.K_OTHER), key=lambda k: per_kernel[L.KERNEL_NAMES[k]][0])
 
     # ---- timed region: exactly K steps, only the dominant kernel bracketed by HIP events -----------
     ctx.profileReset()
@@ -204,7 +204,8 @@ def main():
         "radix_hist": 4 * rec_passes,                          # 4 B index per record per pass
         "radix_scatter": 16 * rec_passes - 4 * vox_in,         # (index,id) in and out; pass 0 has no id to read
         "run_segments": 8 * vox_in + 4 * vox_out,              # index read twice, run starts written
-        "centroid": 20 * vox_in + 16 * vox_out,                # id + gathered point in, centroid out
+        "centroid": 20 * nv + 16 * (m1_total // world),        # per-frame grids: id + gathered point in, centroid out
+        "centroid_runs": 16 * merge_n + 16 * m2,               # merge: points in (runs are contiguous), cells out
     }
     dom_name = L.KERNEL_NAMES[dom]
     achieved = bytes_per_step[dom_name] * args.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

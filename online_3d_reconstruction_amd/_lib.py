@@ -13,9 +13,9 @@ OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_NOT_CONFIGURED, ERR_ALLOC = -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_VOXEL_OVERFLOW = 1
-K_COUNT, K_REPROJECT, K_KEYGEN, K_SORT_HIST, K_SORT_SCATTER, K_SEGMENT, K_CENTROID, K_OTHER = range(8)
+K_COUNT, K_REPROJECT, K_KEYGEN, K_SORT_HIST, K_SORT_SCATTER, K_SEGMENT, K_CENTROID, K_OTHER, K_CENTROID_RUNS = range(9)
 KERNEL_NAMES = ["reproject_count", "reproject_emit", "voxel_keys", "radix_hist", "radix_scatter", "run_segments",
-                "centroid", "other"]
+                "centroid", "other", "centroid_runs"]
 
 
 class O3drError(RuntimeError):

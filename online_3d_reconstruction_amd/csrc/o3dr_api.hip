@@ -57,6 +57,7 @@ struct o3dr_ctx {
     QLutEntry* q_lut = nullptr;  // device table for rectified-stereo Q (nullptr: general 4x4 product per pixel)
     bool q_lut_on = false;
     int max_batch = 256;  // frames per launch group (O3DR_BATCH_FRAMES); also bounded by a workspace budget
+    int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs
     int scatter_ballot = 0;  // O3DR_SCATTER=ballot: the ballot-matching scatter instead of the lane-counting one
     int single_pass = 0;  // sort variant: 1 = look-back single-pass scatter, 0 = histogram/scan/scatter per pass
 
@@ -150,6 +151,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_vals1 = off; off += align256(E * 4);
         size_t o_seg = off;   off += align256(E * 4);
         size_t o_keep = off;  off += align256(E * 4);
+        size_t o_rs = off;    off += align256(E * 4);
         size_t o_tile = off;  off += align256(TE * 4);
         size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
@@ -165,6 +167,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_no = off;    off += align256((size_t)F * 4);
         size_t o_oo = off;    off += align256((size_t)F * 8);
         size_t o_geom = off;  off += align256((size_t)F * sizeof(VoxelGeom));
+        size_t o_geomr = off; off += align256((size_t)F * sizeof(VoxelGeom));
+        size_t o_nr = off;    off += align256((size_t)F * 4);
         CHK(dev_ensure(c, c->ws_block, off));
         char* base = (char*)c->ws_block.p;
         Workspace& w = c->ws;
@@ -174,6 +178,9 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.vals[1] = (uint32_t*)(base + o_vals1);
         w.seg_start = (uint32_t*)(base + o_seg);
         w.keep_idx = (uint32_t*)(base + o_keep);
+        w.run_start = (uint32_t*)(base + o_rs);
+        w.geom_runs = (VoxelGeom*)(base + o_geomr);
+        w.n_runs = (uint32_t*)(base + o_nr);
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
@@ -309,6 +316,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     c->single_pass = (sort_env && strcmp(sort_env, "lookback") == 0) ? 1 : 0;
     const char* hb_env = getenv("O3DR_HOST_BATCH_FRAMES");
     if (hb_env && atoi(hb_env) > 0) c->host_batch = atoi(hb_env);
+    const char* ru_env = getenv("O3DR_RUNS");
+    if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;
     const char* sc_env = getenv("O3DR_SCATTER");
     c->scatter_ballot = (sc_env && strcmp(sc_env, "ballot") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
@@ -608,6 +617,7 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
         v.passthrough = 0;
         v.mm_used = (int)((g.n + kEmitTile - 1) / kEmitTile) + 1;
         v.stats = c->stats_dev;
+        v.use_runs = 0;
         if (sor_on(c)) {  // pose_functions.cpp:1673-1686 in front of the per-frame voxel grid
             CHK(sor_ensure(c, cap));
             v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap, v.mm_used, 1.0, c->ws.sor_pts,
@@ -728,6 +738,7 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     v.passthrough = 0;
     v.mm_used = mm_used;
     v.stats = c->stats_dev;
+    v.use_runs = c->use_runs;
     if (do_sor) {
         CHK(sor_ensure(c, n_in));
         v.mm_used = launch_sor(&c->prof, c->stream, c->ws, in_d, c->ws.n_valid, n_in, mm_used, 1.0, c->ws.sor_pts, c->ws.sor_n);
@@ -1046,6 +1057,7 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
             v.cc = c->cc_big;
             v.passthrough = 0;
             v.stats = c->stats_dev;
+            v.use_runs = 0;
             v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, g.n,
                                    (int)((g.n + kEmitTile - 1) / kEmitTile) + 1, 1.0, c->ws.sor_pts, c->ws.sor_n);
             launch_voxel_grid(&c->prof, c->stream, c->ws, v);
@@ -1123,6 +1135,7 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         v.passthrough = c->params.dont_downsample ? 1 : 0;
         v.mm_used = a.n_tiles + 1;
         v.stats = c->stats_dev;
+        v.use_runs = 0;
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         c->cloud_ub += (int64_t)nb * g.n;

@@ -41,6 +41,7 @@ struct VoxelGeom {
     uint32_t n;           // points in this frame
     uint32_t passes;      // radix passes this frame's index needs (0 when overflow)
     uint32_t bpp;         // bits per pass
+    uint32_t buf0;        // buffer (0/1) the first pass reads; sorted records end in buffer (passes + buf0) & 1
 };
 
 // ---- statistical outlier removal (A3b): search grid + threshold, written by k_sor_plan / k_sor_threshold ----
@@ -111,6 +112,9 @@ struct Workspace {
     uint32_t* error_flag = nullptr;    // set when a look-back spin gives up
     uint32_t epoch = 0;                // epoch of the last look-back launch (22 bits used)
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
+    uint32_t* run_start = nullptr; // frames*(cap+1)  first point of every run (run-compressed path)
+    uint32_t* n_runs = nullptr;    // frames
+    VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of runs, records starting in buffer 1
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
     int64_t mm_stride = 0;         // slots per frame
     uint32_t* n_valid = nullptr;   // frames     points per frame after A1
@@ -166,6 +170,7 @@ struct VoxelArgs {
     int passthrough;  // dont_downsample: append the input unchanged
     int mm_used;      // bounding-box slots to fold per frame
     SortStats* stats; // optional device statistics
+    int use_runs;     // sort runs of consecutive equal indices instead of points (whole-cloud calls)
 };
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);

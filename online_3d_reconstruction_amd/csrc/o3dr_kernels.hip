@@ -72,6 +72,12 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* ld
     __syncthreads();
     return r;
 }
+// the buffer (of the ping-pong pair) a frame's records end up in after its sort passes
+__device__ __forceinline__ const uint32_t* sorted_buf(const VoxelGeom& g, const uint32_t* b0, const uint32_t* b1)
+{
+    return ((g.passes + g.buf0) & 1u) ? b1 : b0;
+}
+
 // workgroup min/max of per-thread (lo[3], hi[3]) -> one 6-float slot (min xyz, max xyz); a workgroup
 // without points stores (+inf, -inf).  Slots are reduced by k_voxel_geom: no same-address atomics.
 template <int NW>
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(256) void k_voxel_geom(const float* __restrict__ mm
     g.overflow = 0;
     g.passes = 0;
     g.bpp = 8;
+    g.buf0 = 0;
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
         g.inv[a] = 1.0f / leaf[a];  // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     const uint32_t dmask = (uint32_t)bins - 1u;
     for (int i = threadIdx.x; i < kSortWaves * kMaxRadix; i += kSortThreads) h[i] = 0;
     __syncthreads();
-    const uint32_t* src = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
+    const uint32_t* src = (((pass + g.buf0) & 1) ? keys1 : keys0) + (int64_t)f * cap;
     const int64_t base = (int64_t)tile * kSortTile;
     uint32_t* hw = h + (threadIdx.x >> 6) * kMaxRadix;
     if (base < n) {
@@ -785,10 +792,11 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
     const int bpp = (int)g.bpp, bins = 1 << bpp, shift = pass * bpp;
     const uint32_t dmask = (uint32_t)bins - 1u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t* kin = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
-    const uint32_t* vin = ((pass & 1) ? vals1 : vals0) + (int64_t)f * cap;
-    uint32_t* kout = ((pass & 1) ? keys0 : keys1) + (int64_t)f * cap;
-    uint32_t* vout = ((pass & 1) ? vals0 : vals1) + (int64_t)f * cap;
+    const int par = (pass + (int)g.buf0) & 1;  // which of the two buffers this pass reads
+    const uint32_t* kin = (par ? keys1 : keys0) + (int64_t)f * cap;
+    const uint32_t* vin = (par ? vals1 : vals0) + (int64_t)f * cap;
+    uint32_t* kout = (par ? keys0 : keys1) + (int64_t)f * cap;
+    uint32_t* vout = (par ? vals0 : vals1) + (int64_t)f * cap;
 
     for (int i = threadIdx.x; i < kSortWaves * kMaxRadix; i += kSortThreads) wave_cnt[i] = 0;
     __syncthreads();
@@ -960,10 +968,11 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lane(uint32_t* _
     const int bpp = (int)g.bpp, bins = 1 << bpp, shift = pass * bpp;
     const uint32_t dmask = (uint32_t)bins - 1u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t* kin = ((pass & 1) ? keys1 : keys0) + (int64_t)f * cap;
-    const uint32_t* vin = ((pass & 1) ? vals1 : vals0) + (int64_t)f * cap;
-    uint32_t* kout = ((pass & 1) ? keys0 : keys1) + (int64_t)f * cap;
-    uint32_t* vout = ((pass & 1) ? vals0 : vals1) + (int64_t)f * cap;
+    const int par = (pass + (int)g.buf0) & 1;  // which of the two buffers this pass reads
+    const uint32_t* kin = (par ? keys1 : keys0) + (int64_t)f * cap;
+    const uint32_t* vin = (par ? vals1 : vals0) + (int64_t)f * cap;
+    uint32_t* kout = (par ? keys0 : keys1) + (int64_t)f * cap;
+    uint32_t* vout = (par ? vals0 : vals1) + (int64_t)f * cap;
 
     for (int i = threadIdx.x; i < kRankWords; i += kSortThreads) smem[i] = 0;
     __syncthreads();
@@ -1095,21 +1104,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lane(uint32_t* _
 //   third/fourth pass of VoxelGrid::applyFilter + CentroidPoint<PointXYZRGB>
 //   [PCL 1.8 common/impl/accumulators.hpp: fp32 sums, xyz / n, uint32_t(channel / n)]
 // =================================================================================================
-__device__ __forceinline__ const uint32_t* sorted_buf(const VoxelGeom& g, const uint32_t* b0, const uint32_t* b1)
-{
-    return (g.passes & 1u) ? b1 : b0;
-}
 
+// buf_sel < 0: the frame's sorted buffer; 0/1: that buffer as is (runs of an UNSORTED sequence)
 __global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ keys1,
                                                    int64_t cap, const VoxelGeom* __restrict__ geom, int n_tiles,
-                                                   uint32_t* __restrict__ seg_cnt)
+                                                   uint32_t* __restrict__ seg_cnt, int buf_sel)
 {
     __shared__ uint32_t lds[4];
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom[f];
     if (g.overflow) return;
     const uint32_t n = g.n;
-    const uint32_t* k = sorted_buf(g, keys0, keys1) + (int64_t)f * cap;
+    const uint32_t* k = (buf_sel < 0 ? sorted_buf(g, keys0, keys1) : (buf_sel ? keys1 : keys0)) + (int64_t)f * cap;
     uint32_t c = 0;
     const int64_t base = (int64_t)tile * kSegTile;
     if (base < n) {
@@ -1129,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__
                                                     int64_t cap, const VoxelGeom* __restrict__ geom, int n_tiles,
                                                     const uint32_t* __restrict__ seg_off,
                                                     const uint32_t* __restrict__ n_vox,
-                                                    uint32_t* __restrict__ seg_start)
+                                                    uint32_t* __restrict__ seg_start, int buf_sel)
 {
     __shared__ uint32_t scan_lds[5];
     const int f = blockIdx.y, tile = blockIdx.x;
@@ -1138,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__
     const uint32_t n = g.n;
     const int64_t base = (int64_t)tile * kSegTile;
     if (base >= n) return;
-    const uint32_t* k = sorted_buf(g, keys0, keys1) + (int64_t)f * cap;
+    const uint32_t* k = (buf_sel < 0 ? sorted_buf(g, keys0, keys1) : (buf_sel ? keys1 : keys0)) + (int64_t)f * cap;
     uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
     if (tile == 0 && threadIdx.x == 0) ss[n_vox[f]] = n;  // sentinel: end of the last run
     uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
@@ -1207,7 +1213,8 @@ __global__ __launch_bounds__(256) void k_keep_write(const uint32_t* __restrict__
 __global__ __launch_bounds__(256) void k_frame_offsets(const VoxelGeom* __restrict__ geom, const uint32_t* __restrict__ n_vox,
                                                        const uint32_t* __restrict__ n_keep, int frames, int passthrough,
                                                        uint32_t* __restrict__ n_out, uint64_t* __restrict__ out_off,
-                                                       CloudCounters* __restrict__ cc, SortStats* __restrict__ stats)
+                                                       CloudCounters* __restrict__ cc, SortStats* __restrict__ stats,
+                                                       const VoxelGeom* __restrict__ sort_geom)
 {
     __shared__ uint32_t scan_lds[5];
     __shared__ unsigned long long acc[4];  // record-passes, points in, points out, status
@@ -1227,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_frame_offsets(const VoxelGeom* __restri
                 atomicOr(&acc[3], (unsigned long long)O3DR_STATUS_VOXEL_OVERFLOW);
             } else {
                 m = n_keep ? n_keep[f] : n_vox[f];
-                atomicAdd(&acc[0], (unsigned long long)g.n * g.passes);
+                atomicAdd(&acc[0], (unsigned long long)sort_geom[f].n * g.passes);  // records actually sorted
                 atomicAdd(&acc[1], (unsigned long long)g.n);
                 atomicAdd(&acc[2], (unsigned long long)m);
             }
@@ -1306,6 +1313,178 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
         }
     }
     const float nf = (float)(e - b);
+    const float cx = sx / nf, cy = sy / nf, cz = sz / nf - z_offset;
+    const uint32_t rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) | ((uint32_t)(sg / nf) << 8) |
+                          (uint32_t)(sb / nf);
+    dst[o] = make_uint4(__float_as_uint(cx), __float_as_uint(cy), __float_as_uint(cz), rgba);
+}
+
+// =================================================================================================
+// Run-compressed voxel grid (used for whole-cloud calls: the combined merge, o3dr_voxel_grid).
+// Inputs of those calls are mostly concatenations of clouds that are already in voxel order, so
+// consecutive points very often share a voxel.  A maximal block of consecutive points with the same
+// index is a RUN; sorting runs (index, run id) instead of points is the same stable order with several
+// times fewer records, and a voxel's points are then read as a few contiguous blocks instead of one
+// gather per point.  Results are bit-identical to the per-point path.
+// =================================================================================================
+__global__ void k_run_geom(const VoxelGeom* __restrict__ geom, const uint32_t* __restrict__ n_runs, int frames,
+                           VoxelGeom* __restrict__ geom_runs)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    VoxelGeom g = geom[f];
+    g.n = g.overflow ? 0u : n_runs[f];
+    g.buf0 = 1;  // the run keys are gathered into buffer 1
+    geom_runs[f] = g;
+}
+// run key = index of the run's first point
+__global__ __launch_bounds__(256) void k_run_keys(const uint32_t* __restrict__ keys0, int64_t cap,
+                                                  const uint32_t* __restrict__ run_start,
+                                                  const VoxelGeom* __restrict__ geom_runs, uint32_t* __restrict__ keys1)
+{
+    const int f = blockIdx.y;
+    const VoxelGeom g = geom_runs[f];
+    if (g.overflow) return;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= g.n) return;
+    keys1[(int64_t)f * cap + r] = keys0[(int64_t)f * cap + run_start[(int64_t)f * (cap + 1) + r]];
+}
+// points of voxel v = sum of the lengths of its runs
+__device__ __forceinline__ uint32_t voxel_points(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ rid,
+                                                 const uint32_t* __restrict__ run_start, uint32_t v)
+{
+    uint32_t c = 0;
+    for (uint32_t j = cell_start[v]; j < cell_start[v + 1]; ++j) {
+        const uint32_t r = rid[j];
+        c += run_start[r + 1] - run_start[r];
+    }
+    return c;
+}
+__global__ __launch_bounds__(256) void k_keep_count_runs(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids0,
+                                                         const uint32_t* __restrict__ ids1,
+                                                         const uint32_t* __restrict__ run_start, int64_t cap,
+                                                         const VoxelGeom* __restrict__ geom_runs,
+                                                         const uint32_t* __restrict__ n_vox, uint32_t min_points,
+                                                         int n_tiles, uint32_t* __restrict__ seg_cnt)
+{
+    __shared__ uint32_t lds[4];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const VoxelGeom g = geom_runs[f];
+    if (g.overflow) return;
+    const uint32_t nv = n_vox[f];
+    const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
+    const uint32_t* rid = sorted_buf(g, ids0, ids1) + (int64_t)f * cap;
+    uint32_t c = 0;
+    const int64_t base = (int64_t)tile * kSegTile;
+    if (base < nv) {
+        for (int j = 0; j < kSegTile / 256; ++j) {
+            const int64_t o = base + j * 256 + threadIdx.x;
+            if (o < nv) c += (voxel_points(ss, rid, rs, (uint32_t)o) >= min_points) ? 1u : 0u;
+        }
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[(int64_t)f * n_tiles + tile] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+__global__ __launch_bounds__(256) void k_keep_write_runs(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids0,
+                                                         const uint32_t* __restrict__ ids1,
+                                                         const uint32_t* __restrict__ run_start, int64_t cap,
+                                                         const VoxelGeom* __restrict__ geom_runs,
+                                                         const uint32_t* __restrict__ n_vox, uint32_t min_points,
+                                                         int n_tiles, const uint32_t* __restrict__ seg_off,
+                                                         uint32_t* __restrict__ keep_idx)
+{
+    __shared__ uint32_t scan_lds[5];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const VoxelGeom g = geom_runs[f];
+    if (g.overflow) return;
+    const uint32_t nv = n_vox[f];
+    const int64_t base = (int64_t)tile * kSegTile;
+    if (base >= nv) return;
+    const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
+    const uint32_t* rid = sorted_buf(g, ids0, ids1) + (int64_t)f * cap;
+    uint32_t* ki = keep_idx + (int64_t)f * cap;
+    uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
+    for (int j = 0; j < kSegTile / 256; ++j) {
+        const int64_t o = base + j * 256 + threadIdx.x;
+        const bool keep = (o < nv) && (voxel_points(ss, rid, rs, (uint32_t)o) >= min_points);
+        uint32_t total;
+        const uint32_t pos = block_excl_scan_u32<4>(keep ? 1u : 0u, scan_lds, total);
+        if (keep) ki[off + pos] = (uint32_t)o;
+        off += total;
+    }
+}
+
+// centroid of voxel o: its runs in sorted (= input) order, each run a contiguous block of points
+__global__ __launch_bounds__(kPtThreads) void k_centroid_runs(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                              const uint32_t* __restrict__ ids0,
+                                                              const uint32_t* __restrict__ ids1, int64_t cap,
+                                                              const uint32_t* __restrict__ seg_start,
+                                                              const uint32_t* __restrict__ run_start,
+                                                              const uint32_t* __restrict__ keep_idx,
+                                                              const VoxelGeom* __restrict__ geom_runs,
+                                                              const uint32_t* __restrict__ n_out,
+                                                              const uint64_t* __restrict__ out_off, float z_offset,
+                                                              o3dr_point* __restrict__ out_base)
+{
+    const int f = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
+    if (o >= n_out[f]) return;
+    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+    uint4* dst = reinterpret_cast<uint4*>(out_base + out_off[f]);
+    const VoxelGeom g = geom_runs[f];
+    if (g.overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
+        uint4 v = src[o];
+        v.z = __float_as_uint((__uint_as_float(v.z) + z_offset) - z_offset);
+        dst[o] = v;
+        return;
+    }
+    const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
+    const uint32_t* rid = sorted_buf(g, ids0, ids1) + (int64_t)f * cap;
+    const uint32_t v = keep_idx ? keep_idx[(int64_t)f * cap + o] : (uint32_t)o;
+    const uint32_t jb = ss[v], je = ss[v + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
+    uint32_t n_pts = 0;
+    // the sums are strictly sequential; loads run ahead: 4 runs' bounds, then up to 4 points of a run
+    for (uint32_t j = jb; j < je; j += 4) {
+        uint32_t b[4], e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b[k] = e[k] = 0;
+            if (j + k < je) {
+                const uint32_t r = rid[j + k];
+                b[k] = rs[r];
+                e[k] = rs[r + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            for (uint32_t i = b[k]; i < e[k]; i += 4) {
+                uint4 p[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i + q < e[k]) p[q] = src[i + q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i + q < e[k]) {
+                        sx += __uint_as_float(p[q].x);
+                        sy += __uint_as_float(p[q].y);
+                        sz += __uint_as_float(p[q].z) + z_offset;
+                        sr += (float)((p[q].w >> 16) & 255u);
+                        sg += (float)((p[q].w >> 8) & 255u);
+                        sb += (float)(p[q].w & 255u);
+                        sa += (float)(p[q].w >> 24);
+                    }
+                }
+            }
+            n_pts += e[k] - b[k];
+        }
+    }
+    const float nf = (float)n_pts;
     const float cx = sx / nf, cy = sy / nf, cz = sz / nf - z_offset;
     const uint32_t rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) | ((uint32_t)(sg / nf) << 8) |
                           (uint32_t)(sb / nf);
@@ -1460,6 +1639,7 @@ __global__ __launch_bounds__(256) void k_sor_plan(const float* __restrict__ mm, 
     for (int a = 0; a < 3; ++a) v.inv[a] = 1.f, v.min_b[a] = 0, v.div_b[a] = 1;
     v.mul1 = v.mul2 = 1;
     v.n = g.n;
+    v.buf0 = 0;
     v.overflow = g.active ? 0u : 1u;  // inactive: every sort kernel returns at once
     const uint64_t cells = (uint64_t)gx * (uint64_t)gy;
     uint32_t nbits = cells > 1 ? 64u - (uint32_t)__clzll((long long)(cells - 1)) : 1u;
@@ -1501,8 +1681,8 @@ __global__ __launch_bounds__(256) void k_sor_cell_table(const o3dr_point* __rest
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= g.n) return;
     const VoxelGeom vg = geom[0];
-    const uint32_t* k = (vg.passes & 1u) ? keys1 : keys0;
-    const uint32_t* id = (vg.passes & 1u) ? ids1 : ids0;
+    const uint32_t* k = sorted_buf(vg, keys0, keys1);
+    const uint32_t* id = sorted_buf(vg, ids0, ids1);
     const uint4 v = reinterpret_cast<const uint4*>(in)[id[j]];
     sxyz[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), 0.f);
     const uint32_t c = k[j];
@@ -1556,7 +1736,7 @@ __global__ __launch_bounds__(kSorThreads) void k_sor_knn(const float4* __restric
     for (int k = 0; k < K; ++k) heap[k][t] = __builtin_huge_valf();  // all-equal values form a valid heap
     const float4 qv = sxyz[i];
     const float qx = qv.x, qy = qv.y, qz = qv.z;
-    const uint32_t out_index = ((geom[0].passes & 1u) ? ids1 : ids0)[i];
+    const uint32_t out_index = sorted_buf(geom[0], ids0, ids1)[i];
     int cx, cy;
     sor_cell(g, qx, qy, cx, cy);
     float worst = __builtin_huge_valf();  // heap root = 51st smallest so far
@@ -1787,6 +1967,9 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                                        v.z_offset, ws.geom);
     }
     uint32_t* n_keep = nullptr;
+    // run compression: whole-cloud calls only, and not together with the look-back variant
+    const bool use_runs = v.use_runs && !ws.single_pass && !v.passthrough;
+    const VoxelGeom* sort_geom = use_runs ? ws.geom_runs : ws.geom;  // what the sort and the run/cell kernels count
     if (!v.passthrough && cap > 0) {
         const dim3 grid(n_sort_tiles, F);
         if (ws.single_pass) {
@@ -1821,35 +2004,54 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, ws.geom,
                                                                                         v.z_offset, cap, ws.keys[0]);
             }
-            // always 4 launches; frames whose index needs fewer passes drop out on the device
+            if (use_runs) {
+                // runs of consecutive equal indices -> (run key, run id) records in buffer 1
+                const dim3 rgrid(n_seg_tiles, F);
+                {
+                    ProfScope ps(pf, O3DR_K_SEGMENT, s);
+                    k_run_heads<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, 0);
+                }
+                {
+                    ProfScope ps(pf, O3DR_K_OTHER, s);
+                    launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_runs, nullptr, ws.scan_partial);
+                }
+                {
+                    ProfScope ps(pf, O3DR_K_SEGMENT, s);
+                    k_run_starts<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
+                                                      ws.run_start, 0);
+                    k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs);
+                    k_run_keys<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(ws.keys[0], cap, ws.run_start, ws.geom_runs, ws.keys[1]);
+                }
+            }
+            // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
             const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
             for (int pass = 0; pass < kMaxPasses; ++pass) {
                 {
                     ProfScope ps(pf, O3DR_K_SORT_HIST, s);
-                    k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles,
+                    k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, pass, n_sort_tiles,
                                                               ws.hist);
                 }
                 {
                     ProfScope ps(pf, O3DR_K_OTHER, s);
-                    launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, ws.geom, pass,
+                    launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, sort_geom, pass,
                                 n_sort_tiles);
                 }
                 {
                     ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
                     if (ws.scatter_ballot)
                         k_radix_scatter<false><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                            ws.geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
+                                                                            sort_geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
                                                                             nullptr, 0u, nullptr);
                     else
                         k_radix_scatter_lane<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                          ws.geom, pass, n_sort_tiles, ws.hist);
+                                                                          sort_geom, pass, n_sort_tiles, ws.hist);
                 }
             }
         }
         const dim3 sgrid(n_seg_tiles, F);
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt);
+            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, -1);
         }
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -1857,14 +2059,18 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         }
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
-                                              ws.seg_start);
+            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
+                                              ws.seg_start, -1);
         }
         if (v.min_points > 1) {
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
-                                                  ws.seg_cnt);
+                if (use_runs)
+                    k_keep_count_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.vals[0], ws.vals[1], ws.run_start, cap, ws.geom_runs,
+                                                           ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt);
+                else
+                    k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
+                                                      ws.seg_cnt);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -1872,8 +2078,12 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             }
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
-                                                  ws.seg_cnt, ws.keep_idx);
+                if (use_runs)
+                    k_keep_write_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.vals[0], ws.vals[1], ws.run_start, cap, ws.geom_runs,
+                                                           ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt, ws.keep_idx);
+                else
+                    k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
+                                                      ws.seg_cnt, ws.keep_idx);
             }
             n_keep = ws.n_out;
         }
@@ -1881,14 +2091,19 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         k_frame_offsets<<<1, 256, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc,
-                                          v.stats);
+                                          v.stats, sort_geom);
     }
     if (cap > 0) {
-        ProfScope ps(pf, O3DR_K_CENTROID, s);
-        k_centroid<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
-            v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start,
-            (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, ws.geom, ws.n_out, ws.out_off, v.z_offset,
-            v.passthrough, v.out_base);
+        ProfScope ps(pf, use_runs ? O3DR_K_CENTROID_RUNS : O3DR_K_CENTROID, s);
+        if (use_runs)
+            k_centroid_runs<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
+                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, ws.run_start,
+                v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.n_out, ws.out_off, v.z_offset, v.out_base);
+        else
+            k_centroid<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
+                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start,
+                (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, ws.geom, ws.n_out, ws.out_off, v.z_offset,
+                v.passthrough, v.out_base);
     }
 }
 
