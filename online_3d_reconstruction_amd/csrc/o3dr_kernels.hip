@@ -1135,7 +1135,8 @@ __global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__
                                                     int64_t cap, const VoxelGeom* __restrict__ geom, int n_tiles,
                                                     const uint32_t* __restrict__ seg_off,
                                                     const uint32_t* __restrict__ n_vox,
-                                                    uint32_t* __restrict__ seg_start, int buf_sel)
+                                                    uint32_t* __restrict__ seg_start, int buf_sel,
+                                                    uint32_t* __restrict__ head_keys_out)
 {
     __shared__ uint32_t scan_lds[5];
     const int f = blockIdx.y, tile = blockIdx.x;
@@ -1154,7 +1155,10 @@ __global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__
         const bool head = (i < n) && (i == 0 || k[i] != k[i - 1]);
         uint32_t total;
         const uint32_t pos = block_excl_scan_u32<4>(head ? 1u : 0u, scan_lds, total);
-        if (head) ss[off + pos] = (uint32_t)i;
+        if (head) {
+            ss[off + pos] = (uint32_t)i;
+            if (head_keys_out) head_keys_out[(int64_t)f * cap + off + pos] = k[i];  // run key = index of its first point
+        }
         off += total;
     }
 }
@@ -1336,18 +1340,6 @@ __global__ void k_run_geom(const VoxelGeom* __restrict__ geom, const uint32_t* _
     g.n = g.overflow ? 0u : n_runs[f];
     g.buf0 = 1;  // the run keys are gathered into buffer 1
     geom_runs[f] = g;
-}
-// run key = index of the run's first point
-__global__ __launch_bounds__(256) void k_run_keys(const uint32_t* __restrict__ keys0, int64_t cap,
-                                                  const uint32_t* __restrict__ run_start,
-                                                  const VoxelGeom* __restrict__ geom_runs, uint32_t* __restrict__ keys1)
-{
-    const int f = blockIdx.y;
-    const VoxelGeom g = geom_runs[f];
-    if (g.overflow) return;
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= g.n) return;
-    keys1[(int64_t)f * cap + r] = keys0[(int64_t)f * cap + run_start[(int64_t)f * (cap + 1) + r]];
 }
 // points of voxel v = sum of the lengths of its runs
 __device__ __forceinline__ uint32_t voxel_points(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ rid,
@@ -2018,9 +2010,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 {
                     ProfScope ps(pf, O3DR_K_SEGMENT, s);
                     k_run_starts<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
-                                                      ws.run_start, 0);
+                                                      ws.run_start, 0, ws.keys[1]);  // run keys gathered into buffer 1
                     k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs);
-                    k_run_keys<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(ws.keys[0], cap, ws.run_start, ws.geom_runs, ws.keys[1]);
                 }
             }
             // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
@@ -2060,7 +2051,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
             k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
-                                              ws.seg_start, -1);
+                                              ws.seg_start, -1, nullptr);
         }
         if (v.min_points > 1) {
             {
