@@ -482,3 +482,28 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
     rbig, rsmall, _ = _oracle_run(orc, Qs, disp, bgr, poses, 0.05, 3, 1)
     assert_points_equal(big, rbig, "cloud_big (streamed host input)")
     assert_points_equal(small, rsmall, "cloud_small (streamed host input)")
+
+
+@pytest.mark.parametrize("env", [{"O3DR_SCATTER": "ballot"}, {"O3DR_SORT": "lookback"}, {"O3DR_RUNS": "0"},
+                                 {"O3DR_NO_QLUT": "1"}, {"O3DR_BATCH_FRAMES": "3"}])
+def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
+    """the A/B variants kept behind environment switches (ballot-matching scatter, look-back single-pass
+    sort, per-point instead of per-run merge, general Q product, small launch groups) give the same bits"""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    Qs = synth.camera_Q()
+    F = 5
+    disp, bgr = synth.make_frames(11, F, invalid_frac=0.02)
+    poses = synth.make_poses(11, F)
+    with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=2, voxel_size=0.05, min_points_per_voxel=2)) as c:
+        c.accumulateFrames(disp, bgr, poses)
+        big = c.cloudBigRead()
+        small = c.finalize()
+        pts = random_cloud(300000, 77)
+        vg = c.voxelGrid(pts, (0.02, 0.03, 0.04), 0)
+    rbig, rsmall, _ = _oracle_run(orc, Qs, disp, bgr, poses, 0.05, 2, 2)
+    assert_points_equal(big, rbig, f"cloud_big {env}")
+    assert_points_equal(small, rsmall, f"cloud_small {env}")
+    assert_points_equal(vg, orc.voxel_grid(pts, (0.02, 0.03, 0.04), 0)[0], f"voxel grid {env}")
