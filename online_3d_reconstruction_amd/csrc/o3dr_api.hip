@@ -152,10 +152,11 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_seg = off;   off += align256(E * 4);
         size_t o_keep = off;  off += align256(E * 4);
         size_t o_rs = off;    off += align256(E * 4);
+        size_t o_rl = off;    off += align256(E * 4);
         size_t o_tile = off;  off += align256(TE * 4);
         size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
-        size_t o_part = off;  off += align256(((TS * kMaxRadix + TG + TE) / 4096 + 4 * (size_t)F + 16) * 4);
+        size_t o_part = off;  off += align256(((TS * kMaxRadix + TG + TE + E) / 4096 + 8 * (size_t)F + 16) * 4);
         size_t o_phist = off; off += align256((size_t)2048 * kMaxPasses * kMaxRadix * 4);  // partial digit histograms
         size_t o_dst = off;   off += align256((size_t)F * kMaxPasses * kMaxRadix * 4);
         size_t o_tick = off;  off += align256((size_t)F * kMaxPasses * 4);
@@ -179,6 +180,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.seg_start = (uint32_t*)(base + o_seg);
         w.keep_idx = (uint32_t*)(base + o_keep);
         w.run_start = (uint32_t*)(base + o_rs);
+        w.run_len = (uint32_t*)(base + o_rl);
         w.geom_runs = (VoxelGeom*)(base + o_geomr);
         w.n_runs = (uint32_t*)(base + o_nr);
         w.tile_cnt = (uint32_t*)(base + o_tile);

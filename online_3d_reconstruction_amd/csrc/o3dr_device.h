@@ -113,6 +113,7 @@ struct Workspace {
     uint32_t epoch = 0;                // epoch of the last look-back launch (22 bits used)
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
     uint32_t* run_start = nullptr; // frames*(cap+1)  first point of every run (run-compressed path)
+    uint32_t* run_len = nullptr;   // frames*(cap+1)  run lengths in sorted order -> exclusive prefix (min_points > 1)
     uint32_t* n_runs = nullptr;    // frames
     VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of runs, records starting in buffer 1
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)

@@ -1341,20 +1341,27 @@ __global__ void k_run_geom(const VoxelGeom* __restrict__ geom, const uint32_t* _
     g.buf0 = 1;  // the run keys are gathered into buffer 1
     geom_runs[f] = g;
 }
-// points of voxel v = sum of the lengths of its runs
-__device__ __forceinline__ uint32_t voxel_points(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ rid,
-                                                 const uint32_t* __restrict__ run_start, uint32_t v)
+// lengths of the runs in sorted order (then scanned in place): points of voxel v = pref[end] - pref[start]
+__global__ __launch_bounds__(256) void k_run_lengths(const uint32_t* __restrict__ ids0, const uint32_t* __restrict__ ids1,
+                                                     const uint32_t* __restrict__ run_start, int64_t cap,
+                                                     const VoxelGeom* __restrict__ geom_runs, uint32_t* __restrict__ len_out)
 {
-    uint32_t c = 0;
-    for (uint32_t j = cell_start[v]; j < cell_start[v + 1]; ++j) {
-        const uint32_t r = rid[j];
-        c += run_start[r + 1] - run_start[r];
+    const int f = blockIdx.y;
+    const VoxelGeom g = geom_runs[f];
+    if (g.overflow) return;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > g.n) return;
+    uint32_t* out = len_out + (int64_t)f * (cap + 1);
+    if (j == g.n) {  // one extra slot so that the exclusive scan yields the grand total at index n
+        out[j] = 0;
+        return;
     }
-    return c;
+    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
+    const uint32_t r = (sorted_buf(g, ids0, ids1) + (int64_t)f * cap)[j];
+    out[j] = rs[r + 1] - rs[r];
 }
-__global__ __launch_bounds__(256) void k_keep_count_runs(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids0,
-                                                         const uint32_t* __restrict__ ids1,
-                                                         const uint32_t* __restrict__ run_start, int64_t cap,
+__global__ __launch_bounds__(256) void k_keep_count_runs(const uint32_t* __restrict__ seg_start,
+                                                         const uint32_t* __restrict__ len_pref, int64_t cap,
                                                          const VoxelGeom* __restrict__ geom_runs,
                                                          const uint32_t* __restrict__ n_vox, uint32_t min_points,
                                                          int n_tiles, uint32_t* __restrict__ seg_cnt)
@@ -1365,14 +1372,13 @@ __global__ __launch_bounds__(256) void k_keep_count_runs(const uint32_t* __restr
     if (g.overflow) return;
     const uint32_t nv = n_vox[f];
     const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
-    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
-    const uint32_t* rid = sorted_buf(g, ids0, ids1) + (int64_t)f * cap;
+    const uint32_t* lp = len_pref + (int64_t)f * (cap + 1);
     uint32_t c = 0;
     const int64_t base = (int64_t)tile * kSegTile;
     if (base < nv) {
         for (int j = 0; j < kSegTile / 256; ++j) {
             const int64_t o = base + j * 256 + threadIdx.x;
-            if (o < nv) c += (voxel_points(ss, rid, rs, (uint32_t)o) >= min_points) ? 1u : 0u;
+            if (o < nv) c += (lp[ss[o + 1]] - lp[ss[o]] >= min_points) ? 1u : 0u;
         }
     }
     c = wave_sum_u32(c);
@@ -1380,9 +1386,8 @@ __global__ __launch_bounds__(256) void k_keep_count_runs(const uint32_t* __restr
     __syncthreads();
     if (threadIdx.x == 0) seg_cnt[(int64_t)f * n_tiles + tile] = lds[0] + lds[1] + lds[2] + lds[3];
 }
-__global__ __launch_bounds__(256) void k_keep_write_runs(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids0,
-                                                         const uint32_t* __restrict__ ids1,
-                                                         const uint32_t* __restrict__ run_start, int64_t cap,
+__global__ __launch_bounds__(256) void k_keep_write_runs(const uint32_t* __restrict__ seg_start,
+                                                         const uint32_t* __restrict__ len_pref, int64_t cap,
                                                          const VoxelGeom* __restrict__ geom_runs,
                                                          const uint32_t* __restrict__ n_vox, uint32_t min_points,
                                                          int n_tiles, const uint32_t* __restrict__ seg_off,
@@ -1396,13 +1401,12 @@ __global__ __launch_bounds__(256) void k_keep_write_runs(const uint32_t* __restr
     const int64_t base = (int64_t)tile * kSegTile;
     if (base >= nv) return;
     const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
-    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
-    const uint32_t* rid = sorted_buf(g, ids0, ids1) + (int64_t)f * cap;
+    const uint32_t* lp = len_pref + (int64_t)f * (cap + 1);
     uint32_t* ki = keep_idx + (int64_t)f * cap;
     uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
     for (int j = 0; j < kSegTile / 256; ++j) {
         const int64_t o = base + j * 256 + threadIdx.x;
-        const bool keep = (o < nv) && (voxel_points(ss, rid, rs, (uint32_t)o) >= min_points);
+        const bool keep = (o < nv) && (lp[ss[o + 1]] - lp[ss[o]] >= min_points);
         uint32_t total;
         const uint32_t pos = block_excl_scan_u32<4>(keep ? 1u : 0u, scan_lds, total);
         if (keep) ki[off + pos] = (uint32_t)o;
@@ -2056,10 +2060,15 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         if (v.min_points > 1) {
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                if (use_runs)
-                    k_keep_count_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.vals[0], ws.vals[1], ws.run_start, cap, ws.geom_runs,
-                                                           ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt);
-                else
+                if (use_runs) {
+                    // points per voxel from a prefix sum over the sorted runs' lengths (stored in keep_idx's
+                    // neighbour array run_len: one pass + one scan instead of walking every voxel's runs twice)
+                    k_run_lengths<<<dim3(cdiv64(cap + 1, 256), F), 256, 0, s>>>(ws.vals[0], ws.vals[1], ws.run_start, cap,
+                                                                             ws.geom_runs, ws.run_len);
+                    launch_scan(s, ws.run_len, cap + 1, cap + 1, F, nullptr, nullptr, ws.scan_partial);
+                    k_keep_count_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
+                                                           n_seg_tiles, ws.seg_cnt);
+                } else
                     k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
                                                       ws.seg_cnt);
             }
@@ -2070,8 +2079,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
                 if (use_runs)
-                    k_keep_write_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.vals[0], ws.vals[1], ws.run_start, cap, ws.geom_runs,
-                                                           ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt, ws.keep_idx);
+                    k_keep_write_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
+                                                           n_seg_tiles, ws.seg_cnt, ws.keep_idx);
                 else
                     k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
                                                       ws.seg_cnt, ws.keep_idx);
