@@ -507,3 +507,17 @@ def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     assert_points_equal(big, rbig, f"cloud_big {env}")
     assert_points_equal(small, rsmall, f"cloud_small {env}")
     assert_points_equal(vg, orc.voxel_grid(pts, (0.02, 0.03, 0.04), 0)[0], f"voxel grid {env}")
+
+
+def test_A1_row_pitch_larger_than_width(ctx, orc, Q, frame_1249):
+    """OpenCV Mats are often ROI views: rows padded (pitch > cols); also the unaligned (generic) load path"""
+    disp0, bgr0 = frame_1249
+    dpad = np.zeros((720, 1280 + 37), np.uint8)
+    cpad = np.zeros((720, 1280 + 11, 3), np.uint8)
+    dpad[:, :1280] = disp0
+    cpad[:, :1280] = bgr0
+    disp, bgr = dpad[:, :1280], cpad[:, :1280]
+    assert disp.strides[0] == 1317 and bgr.strides[0] == 3 * 1291
+    ctx.set_params(_params(jump_pixels=1, voxel_size=0.05))
+    got = ctx.createSingleImgPtCloud(disp, bgr)
+    assert_points_equal(got, orc.create_single_img_pt_cloud(disp0, bgr0, Q, jump_pixels=1), "A1 padded rows")
