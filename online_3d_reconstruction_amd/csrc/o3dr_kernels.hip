@@ -709,18 +709,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
                                                              const VoxelGeom* __restrict__ geom, int pass,
                                                              int n_tiles, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t h[kSortWaves * kMaxRadix];  // one private table per wave: no cross-wave contention
+    // private tables per wave AND per lane quarter (4 x 8 x 128 counters): an LDS add only collides
+    // with the 15 other lanes of its quarter, and those spread over 128 bins
+    constexpr int kSub = 4;
+    __shared__ uint32_t h[kSub * kSortWaves * kMaxRadix];
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom[f];
     if (g.overflow || pass >= (int)g.passes) return;
     const uint32_t n = g.n;
     const int bins = 1 << g.bpp, shift = pass * (int)g.bpp;
     const uint32_t dmask = (uint32_t)bins - 1u;
-    for (int i = threadIdx.x; i < kSortWaves * kMaxRadix; i += kSortThreads) h[i] = 0;
+    for (int i = threadIdx.x; i < kSub * kSortWaves * kMaxRadix; i += kSortThreads) h[i] = 0;
     __syncthreads();
     const uint32_t* src = (((pass + g.buf0) & 1) ? keys1 : keys0) + (int64_t)f * cap;
     const int64_t base = (int64_t)tile * kSortTile;
-    uint32_t* hw = h + (threadIdx.x >> 6) * kMaxRadix;
+    uint32_t* hw = h + (((threadIdx.x >> 6) * kSub) + (threadIdx.x & (kSub - 1))) * kMaxRadix;
     if (base < n) {
         // a histogram does not care which lane sees which record: 16-byte loads, 4 per lane
         const bool vec = (((int64_t)f * cap) & 3) == 0;  // tile bases are multiples of 8192
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) {
         uint32_t t = 0;
 #pragma unroll
-        for (int ww = 0; ww < kSortWaves; ++ww) t += h[ww * kMaxRadix + dgt];
+        for (int ww = 0; ww < kSub * kSortWaves; ++ww) t += h[ww * kMaxRadix + dgt];
         dst[(int64_t)dgt * n_tiles + tile] = t;
     }
 }
