@@ -181,7 +181,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dom_ms, dom_launches = ctx.profileRead(dom)
-    stats = ctx.profileStats()
+    stats = ctx.profileStatsAll()
     ctx.profileEnable(dom, False)
 
     if world > 1:
@@ -194,17 +194,22 @@ def main():
     m1_total, m2 = state["m1_total"], state["m2"]
 
     # ---- algorithmic bytes per step (DESIGN.md "Kernels and rooflines") --------------------------------
-    rec_passes, vox_in, vox_out = (v / args.steps for v in stats)  # device counters over the timed region
+    rec_passes, vox_in, vox_out, win_frames, sort_recs = (v / args.steps for v in stats[:5])  # device counters, per step
     nv = n_valid_total  # valid points of this rank's frames (per step)
     merge_n = m1_total // world  # points entering the combined merge on this rank (its index slice)
+    m1 = m1_total // world       # per-frame voxels of this rank's frames
+    fw = min(1.0, win_frames / F)  # share of the frames on the pixel-window path (voxels formed in image tiles)
+    fg = 1.0 - fw
+    merge_in = vox_in - nv       # points that entered whole-cloud grids (the merge), not per-frame ones
     bytes_per_step = {
-        "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate
-        "reproject_emit": 4 * n_cand * F + 16 * nv,            # 1 B disparity + 3 B colour in, 16 B point out
-        "voxel_keys": 20 * vox_in,                             # 16 B point in, 4 B index out
+        "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate (+ the frame's bounding box)
+        "reproject_emit": fg * (4 * n_cand * F + 16 * nv),     # sort path: 1 B disparity + 3 B colour in, 16 B point out
+        "window_group": fw * (4 * n_cand * F + 20 * m1),       # window path: same pixels in, (index, centroid) per voxel out
+        "voxel_keys": 20 * (fg * nv + merge_in),               # 16 B point in, 4 B index out
         "radix_hist": 4 * rec_passes,                          # 4 B index per record per pass
-        "radix_scatter": 16 * rec_passes - 4 * vox_in,         # (index,id) in and out; pass 0 has no id to read
-        "run_segments": 8 * vox_in + 4 * vox_out,              # index read twice, run starts written
-        "centroid": 20 * nv + 16 * (m1_total // world),        # per-frame grids: id + gathered point in, centroid out
+        "radix_scatter": 16 * rec_passes - 4 * sort_recs,      # (index,id) in and out; pass 0 has no id to read
+        "run_segments": 8 * (fg * nv + merge_in) + 4 * vox_out,  # index read twice, run starts written
+        "centroid": fg * (20 * nv + 16 * m1) + fw * 36 * m1,   # sort path: id + gathered point in, centroid out; window path: id + record in, point out
         "centroid_runs": 16 * merge_n + 16 * m2,               # merge: points in (runs are contiguous), cells out
     }
     dom_name = L.KERNEL_NAMES[dom]
@@ -214,6 +219,23 @@ def main():
                 "traffic": None,
                 "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2), "launches": int(dom_launches),
                 "algorithmic_bytes_per_launch": int(bytes_per_step[dom_name] * args.steps / max(dom_launches, 1))}
+    # what a plain device-to-device copy reaches on this box (read + write bytes): context for `peak`
+    try:
+        src_t = torch.empty(1 << 28, dtype=torch.int32, device=dev)  # 1 GiB
+        dst_t = torch.empty_like(src_t)
+        for _ in range(2):
+            dst_t.copy_(src_t)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst_t.copy_(src_t)
+        e1.record()
+        torch.cuda.synchronize()
+        roofline["measured_copy_GBps"] = round(5 * 2 * src_t.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src_t, dst_t
+    except Exception:
+        roofline["measured_copy_GBps"] = None
     traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(traffic_file):
         try:
@@ -243,6 +265,8 @@ def main():
         "end_to_end": {"algorithmic_GBps": round(e2e_gbs, 2), "frac_of_hbm_peak": round(e2e_gbs / HBM_PEAK_GBS / world, 5),
                        "bytes_per_frame": int(b_frame), "bytes_final_merge": int(b_final)},
         "kernel_ms_per_step": {k: round(v[0], 3) for k, v in per_kernel.items()},
+        "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes),
+                 "frames_on_window_path_per_step": int(win_frames)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -228,7 +228,8 @@ int o3dr_cloud_big_adopt(o3dr_ctx* ctx, int64_t n_points);
 #define O3DR_K_CENTROID     6  /* ordered per-voxel sums -> centroid */
 #define O3DR_K_OTHER        7  /* scans, grid setup, copies */
 #define O3DR_K_CENTROID_RUNS 8 /* ordered per-voxel sums over runs of points (whole-cloud calls) */
-#define O3DR_K_NUM          9
+#define O3DR_K_WINDOW       9  /* fused reproject + SE(3) + in-tile voxel grouping (pixel-window path of A6) */
+#define O3DR_K_NUM          10
 /* Bracket every launch of kernel `kernel_id` (or all kernels if -1) with HIP events on the
  * context's stream; 0 launches are bracketed when disabled (the default). */
 int o3dr_profile_enable(o3dr_ctx* ctx, int32_t kernel_id, int32_t enable);
@@ -236,9 +237,11 @@ int o3dr_profile_enable(o3dr_ctx* ctx, int32_t kernel_id, int32_t enable);
 int o3dr_profile_read(o3dr_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
 int o3dr_profile_reset(o3dr_ctx* ctx);
 /* Synchronises; counters since the last o3dr_profile_reset, for algorithmic-byte accounting:
- * out[0] = sum over voxel grids of (points x radix passes actually run), out[1] = points that entered
- * voxel grids, out[2] = points that left them, out[3] = 0. */
-int o3dr_profile_stats(o3dr_ctx* ctx, int64_t out[4]);
+ * out[0] = sum over voxel grids of (records x radix passes actually run), out[1] = points that entered
+ * voxel grids, out[2] = points that left them, out[3] = frames of o3dr_accumulate_frames batches that took the
+ * pixel-window path (voxels formed inside image tiles; only their records are sorted), out[4] = records that
+ * entered the sorts (points, runs of points, or voxel records), out[5..7] = 0. */
+int o3dr_profile_stats(o3dr_ctx* ctx, int64_t out[8]);
 /* device name / arch / CU count of the context's device, for bench headers */
 int o3dr_device_info(o3dr_ctx* ctx, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
 

@@ -15,7 +15,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_VOXEL_OVERFLOW = 1
 K_COUNT, K_REPROJECT, K_KEYGEN, K_SORT_HIST, K_SORT_SCATTER, K_SEGMENT, K_CENTROID, K_OTHER, K_CENTROID_RUNS = range(9)
 KERNEL_NAMES = ["reproject_count", "reproject_emit", "voxel_keys", "radix_hist", "radix_scatter", "run_segments",
-                "centroid", "other", "centroid_runs"]
+                "centroid", "other", "centroid_runs", "window_group"]
 
 
 class O3drError(RuntimeError):

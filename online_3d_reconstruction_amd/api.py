@@ -348,9 +348,17 @@ class Context:
 
     def profileStats(self):
         """(sort record-passes, voxel-grid points in, voxel-grid points out) since profileReset()"""
-        out = (C.c_int64 * 4)()
+        return self.profileStats4()[:3]
+
+    def profileStats4(self):
+        """profileStats() + the number of frames that took the pixel-window path"""
+        return self.profileStatsAll()[:4]
+
+    def profileStatsAll(self):
+        """all eight counters of o3dr_profile_stats (include/o3dr.h)"""
+        out = (C.c_int64 * 8)()
         L.check(self._lib.o3dr_profile_stats(self._h, out))
-        return int(out[0]), int(out[1]), int(out[2])
+        return tuple(int(v) for v in out)
 
     def profileRead(self, kernel_id):
         ms = C.c_double(0)

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <cmath>
 #include <string>
 
 #include "o3dr_device.h"
@@ -56,6 +58,12 @@ struct o3dr_ctx {
     bool has_Q = false;
     QLutEntry* q_lut = nullptr;  // device table for rectified-stereo Q (nullptr: general 4x4 product per pixel)
     bool q_lut_on = false;
+    // pixel-window path of o3dr_accumulate_frames (opt-in, O3DR_WINDOW=1: bit-exact but measured slower than the
+    // sort-based path): per-disparity table
+    float* win_tab = nullptr;       // device, 512 floats
+    float* win_tab_host = nullptr;  // pinned
+    int win_enable = 0;
+    bool win_tab_valid = false;
     int max_batch = 256;  // frames per launch group (O3DR_BATCH_FRAMES); also bounded by a workspace budget
     int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs
     int scatter_ballot = 0;  // O3DR_SCATTER=ballot: the ballot-matching scatter instead of the lane-counting one
@@ -170,6 +178,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_geom = off;  off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_geomr = off; off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_nr = off;    off += align256((size_t)F * 4);
+        size_t o_geomg = off; off += align256((size_t)F * sizeof(VoxelGeom));
+        size_t o_winc = off;  off += align256((size_t)F * 2 * sizeof(float));
         CHK(dev_ensure(c, c->ws_block, off));
         char* base = (char*)c->ws_block.p;
         Workspace& w = c->ws;
@@ -183,6 +193,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.run_len = (uint32_t*)(base + o_rl);
         w.geom_runs = (VoxelGeom*)(base + o_geomr);
         w.n_runs = (uint32_t*)(base + o_nr);
+        w.geom_gen = (VoxelGeom*)(base + o_geomg);
+        w.win_c = (float*)(base + o_winc);
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
@@ -304,6 +316,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
         hipHostMalloc((void**)&c->misc_host, 4096, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->misc_host_lut, 256 * sizeof(QLutEntry), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->q_lut, 256 * sizeof(QLutEntry)) != hipSuccess ||
+        hipMalloc((void**)&c->win_tab, 512 * sizeof(float)) != hipSuccess ||
+        hipHostMalloc((void**)&c->win_tab_host, 512 * sizeof(float), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->stats_host, sizeof(SortStats), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(O3DR_ERR_ALLOC, "counter allocation failed");
@@ -320,6 +334,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (hb_env && atoi(hb_env) > 0) c->host_batch = atoi(hb_env);
     const char* ru_env = getenv("O3DR_RUNS");
     if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;
+    const char* wi_env = getenv("O3DR_WINDOW");
+    c->win_enable = (wi_env && atoi(wi_env) == 1) ? 1 : 0;
     const char* sc_env = getenv("O3DR_SCATTER");
     c->scatter_ballot = (sc_env && strcmp(sc_env, "ballot") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
@@ -353,6 +369,8 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->misc_host) (void)hipHostFree(c->misc_host);
     if (c->misc_host_lut) (void)hipHostFree(c->misc_host_lut);
     if (c->q_lut) (void)hipFree(c->q_lut);
+    if (c->win_tab) (void)hipFree(c->win_tab);
+    if (c->win_tab_host) (void)hipHostFree(c->win_tab_host);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
     for (int i = 0; i < 2; ++i) {
         dev_release(c->st2_disp[i]);
@@ -499,6 +517,62 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
     a.out_fstride = out_fstride;
     a.mm_stride = c->ws.mm_stride;
     a.lut = c->q_lut_on ? c->q_lut : nullptr;
+}
+
+// Pixel-window voxel grouping (o3dr_kernels.hip): decide whether a fused A6 batch may use it and build the
+// per-disparity table.  With a rectified-stereo Q:
+//   * depth is a function of the disparity byte alone; if all valid levels are more than kWinCMax * leaf apart
+//     (an upper bound of how far two points of one voxel can be apart along any camera axis), two pixels of one
+//     voxel carry the same disparity;
+//   * at disparity d one candidate step moves X by jump * |Q0 / w(d)| and Y by jump * |Q5 / w(d)|, so pixels of one
+//     voxel are at most floor(c * leaf / step) candidates apart along each image axis.  The factor c <= kWinCMax
+//     comes from the frame's pose (k_window_plan); the table holds leaf / step.
+// Frames whose pose is not rigid or too far out for the rounding budget, and frames under PCL's overflow guard,
+// take the sort-based path inside the same launches.
+static bool window_plan(o3dr_ctx* c, const GridShape& g, int rows, int cols, float leaf, WindowPlan* w)
+{
+    if (!c->win_enable || !c->q_lut_on || c->single_pass || c->params.dont_downsample || c->params.jump_pixels < 1) return false;
+    const QLutEntry* lut = (const QLutEntry*)c->misc_host_lut;
+    const double* Q = c->Q;
+    if (Q[0] == 0.0 || Q[5] == 0.0 || !(leaf > 0.f)) return false;
+    const double reach = (double)kWinCMax * (double)leaf;
+    const double xm = fmax(fabs(Q[0] * (double)g.cs + Q[3]), fabs(Q[0] * (double)cols + Q[3]));
+    const double ym = fmax(fabs(Q[5] * 0.0 + Q[7]), fabs(Q[5] * (double)rows + Q[7]));
+    double rho = 0.0, zs[256];
+    int nz = 0;
+    float tab[512];
+    for (int d = 0; d < 256; ++d) {
+        tab[d] = tab[256 + d] = 0.f;
+        if (!((double)d > c->params.min_disparity)) continue;
+        const double al = fabs(lut[d].alpha), z = (double)lut[d].z;
+        if (!(al > 0.0) || !std::isfinite(al) || !std::isfinite(z)) return false;
+        zs[nz++] = z;
+        const double bu = (double)leaf / (fabs(Q[0]) * al * c->params.jump_pixels);
+        const double bv = (double)leaf / (fabs(Q[5]) * al * c->params.jump_pixels);
+        if ((double)kWinCMax * bu * 1.00001 >= (double)kWinHalo + 1.0 || (double)kWinCMax * bv * 1.00001 >= (double)kWinHalo + 1.0)
+            return false;  // a radius could exceed the halo the tile kernel supports
+        tab[d] = nextafterf((float)bu, INFINITY);
+        tab[256 + d] = nextafterf((float)bv, INFINITY);
+        const double r = sqrt((xm * al) * (xm * al) + (ym * al) * (ym * al) + z * z);
+        if (r > rho) rho = r;
+    }
+    if (nz == 0) return false;
+    std::sort(zs, zs + nz);
+    for (int i = 1; i < nz; ++i)
+        if (!(zs[i] - zs[i - 1] > reach)) return false;  // two depth levels could meet in one voxel
+    if (!c->win_tab_valid || memcmp(tab, c->win_tab_host, sizeof tab) != 0) {
+        // earlier batches may still be reading the device table (and an upload the pinned one): drain first
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+        memcpy(c->win_tab_host, tab, sizeof tab);
+        if (hipMemcpyAsync(c->win_tab, c->win_tab_host, sizeof tab, hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
+        c->win_tab_valid = true;
+    }
+    w->wbase = c->win_tab;
+    w->rho_max = (float)rho;
+    // rounding may stretch the distance of two points by 2 err per axis; k_window_plan's factor allows 0.025 leaf each
+    w->err_budget = (float)(0.025 * (double)leaf);
+    w->n_kp = c->ws.n_kp;
+    return true;
 }
 
 // stage a host buffer into HBM (or pass a device pointer through)
@@ -1076,6 +1150,8 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }
     CHK(ws_ensure(c, B, g.n, true));
+    WindowPlan wplan;
+    const bool use_window = window_plan(c, g, rows, cols, leaf[0], &wplan);
 
     const bool streaming = mem == O3DR_MEM_HOST;
     if (streaming) {
@@ -1119,9 +1195,16 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         a.xf_mode = 2;
         a.poses = (const float*)poses_d;
         launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
-        launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
-                     c->ws.scan_partial);
+        if (use_window) {
+            // bounding boxes only; the window kernel inside launch_voxel_grid redoes the reprojection in LDS
+            wplan.a = a;
+            launch_frame_bbox(&c->prof, c->stream, a, nb, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
+                              c->ws.scan_partial);
+        } else
+            launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
+                             c->ws.scan_partial);
         VoxelArgs v;
+        v.window = use_window ? &wplan : nullptr;
         v.in = c->ws.pts;
         v.in_fstride = g.n;
         v.n_dev = c->ws.n_valid;
@@ -1349,7 +1432,7 @@ extern "C" int o3dr_profile_reset(o3dr_ctx* c)
     c->prof.reset();
     return O3DR_OK;
 }
-extern "C" int o3dr_profile_stats(o3dr_ctx* c, int64_t out[4])
+extern "C" int o3dr_profile_stats(o3dr_ctx* c, int64_t out[8])
 {
     CTX_ENTER(c);
     if (!out) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
@@ -1358,7 +1441,9 @@ extern "C" int o3dr_profile_stats(o3dr_ctx* c, int64_t out[4])
     out[0] = (int64_t)c->stats_host->sort_record_passes;
     out[1] = (int64_t)c->stats_host->voxel_points_in;
     out[2] = (int64_t)c->stats_host->voxel_points_out;
-    out[3] = 0;
+    out[3] = (int64_t)c->stats_host->window_frames;
+    out[4] = (int64_t)c->stats_host->sort_records;
+    out[5] = out[6] = out[7] = 0;
     return O3DR_OK;
 }
 extern "C" int o3dr_device_info(o3dr_ctx* c, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes)

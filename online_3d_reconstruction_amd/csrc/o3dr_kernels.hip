@@ -77,6 +77,25 @@ __device__ __forceinline__ const uint32_t* sorted_buf(const VoxelGeom& g, const 
 {
     return ((g.passes + g.buf0) & 1u) ? b1 : b0;
 }
+// Run-compressed sorts carry (first point, length) of a run in the 32-bit payload: the low `bits` bits hold the
+// first point (< n), the rest length - 1.  Runs are cut at multiples of the largest length that fits, which
+// only makes more (shorter) records of one voxel; the stable sort keeps them in order.
+__device__ __forceinline__ uint32_t run_start_bits(uint32_t n) { return n > 1u ? 32u - (uint32_t)__clz(n - 1u) : 1u; }
+__device__ __forceinline__ uint32_t run_split_mask(uint32_t bits) { return bits >= 32u ? 0u : (1u << (32u - bits)) - 1u; }
+__device__ __forceinline__ uint32_t run_pack(uint32_t first, uint32_t next, uint32_t bits)
+{
+    return bits >= 32u ? first : (first | ((next - first - 1u) << bits));
+}
+__device__ __forceinline__ void run_unpack(uint32_t v, uint32_t bits, uint32_t& first, uint32_t& len)
+{
+    if (bits >= 32u) {
+        first = v;
+        len = 1u;
+    } else {
+        first = v & ((1u << bits) - 1u);
+        len = (v >> bits) + 1u;
+    }
+}
 
 // workgroup min/max of per-thread (lo[3], hi[3]) -> one 6-float slot (min xyz, max xyz); a workgroup
 // without points stores (+inf, -inf).  Slots are reduced by k_voxel_geom: no same-address atomics.
@@ -201,8 +220,11 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_count(ReprojectArgs 
 __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a, o3dr_point* __restrict__ out,
                                                                  const uint32_t* __restrict__ tile_off,
                                                                  const uint32_t* __restrict__ n_kp,
-                                                                 float* __restrict__ mm)
+                                                                 float* __restrict__ mm,
+                                                                 const VoxelGeom* __restrict__ gate)
 {
+    // batches on the pixel-window path: only frames left to the sort-based path need the ordered cloud itself
+    if (gate && gate[blockIdx.y].n == 0) return;
     __shared__ uint4 stage[kEmitTile];  // 16 KiB: the tile's points in output order
     __shared__ uint32_t scan_lds[kEmitThreads / 64 + 1];
     __shared__ float mm_lds[6 * (kEmitThreads / 64)];
@@ -504,6 +526,374 @@ __global__ __launch_bounds__(kPtThreads) void k_points_minmax(const o3dr_point* 
 }
 
 // =================================================================================================
+// Pixel-window voxel grouping (fused A6 path, rectified-stereo Q, small leaf).
+//   Two pixels can only fall into the same (voxel_size/5) voxel if they carry the same disparity byte and
+//   lie within W(d) = floor(1.01*leaf*sqrt(3) / (|Q0| * |1/w(d)|)) pixels of each other (the host checks that
+//   neighbouring disparity levels are more than leaf*sqrt(3) apart in depth; o3dr_api.hip).  So voxels are
+//   formed inside an LDS tile with halo: the pixel with the lowest row-major index of a voxel (its head)
+//   adds up the voxel's pixels in row-major order — the same strictly sequential fp32 sums, in the same
+//   order, as the sort-based path — and only the (index, centroid) records of the voxels are sorted.
+// =================================================================================================
+// pass 1: like k_reproject_count, plus the frame's bounding box (it is needed before any voxel index)
+__global__ __launch_bounds__(kEmitThreads) void k_frame_bbox(ReprojectArgs a, uint32_t* __restrict__ tile_cnt,
+                                                             float* __restrict__ mm)
+{
+    __shared__ uint32_t lds[kEmitThreads / 64];
+    __shared__ float mm_lds[6 * (kEmitThreads / 64)];
+    __shared__ double lut_alpha[256];
+    __shared__ float lut_z[256];
+    lut_alpha[threadIdx.x] = a.lut[threadIdx.x].alpha;
+    lut_z[threadIdx.x] = a.lut[threadIdx.x].z;
+    __syncthreads();
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const uint8_t* disp = a.disp + (int64_t)f * a.disp_fstride;
+    const int n_cand = a.Ny * a.Nx;
+    const int c0 = tile * kEmitTile + threadIdx.x * kEmitPerLane;
+    float m[12];
+    const float* T = a.poses + 16 * (int64_t)f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = T[i];
+    int x0 = 0, y0 = 0;
+    uint32_t d[4];
+    const uint32_t valid = load_lane_disparities(a, disp, c0, n_cand, x0, y0, d);
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (valid & (1u << k)) {
+            int x, y;
+            if (a.vec4) {
+                x = x0 + k;
+                y = y0;
+            } else {
+                const int c = c0 + k;
+                const int ry = c / a.Nx, rx = c - ry * a.Nx;
+                y = a.bb + ry * a.jump;
+                x = a.cs + rx * a.jump;
+            }
+            const double al = lut_alpha[d[k]];
+            const float X = (float)((a.Q[0] * (double)x + a.Q[3]) * al + 0.0);
+            const float Y = (float)((a.Q[5] * (double)y + a.Q[7]) * al + 0.0);
+            const float Z = lut_z[d[k]];
+            const float px = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+            const float py = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+            const float pz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+            lo[0] = fminf(lo[0], px); hi[0] = fmaxf(hi[0], px);
+            lo[1] = fminf(lo[1], py); hi[1] = fmaxf(hi[1], py);
+            lo[2] = fminf(lo[2], pz); hi[2] = fmaxf(hi[2], pz);
+        }
+    }
+    const uint32_t sc = wave_sum_u32(__popc(valid));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < kEmitThreads / 64; ++i) t += lds[i];
+        tile_cnt[(int64_t)f * a.n_tiles + tile] = t;
+    }
+    block_minmax_store<kEmitThreads / 64>(lo, hi, valid != 0, mm_lds, mm + ((int64_t)f * a.mm_stride + tile) * 6);
+}
+
+constexpr int kWinTY = 16, kWinTX = 64;          // core tile: 1024 candidates; lane = column, 4 rows per lane
+constexpr int kWinRS = kWinTX + 2 * kWinHalo;    // LDS row stride (fixed, so window offsets are compile-time constants)
+constexpr int kWinRows = kWinTY + 2 * kWinHalo;
+constexpr int kWinPtRows = kWinTY + kWinHalo;    // rows that can hold pixels to be summed (tile + lower halo)
+constexpr int kWinStage = (kWinRows * kWinRS + 255) / 256;  // region pixels per lane
+constexpr uint32_t kNoKey = 0xffffffffu;
+
+__device__ __forceinline__ void win_add(const uint4 p, float& sx, float& sy, float& sz, float& sr, float& sg, float& sb)
+{
+    sx += __uint_as_float(p.x);
+    sy += __uint_as_float(p.y);
+    sz += __uint_as_float(p.z) + 0.0f;
+    sr += (float)((p.w >> 16) & 255u);
+    sg += (float)((p.w >> 8) & 255u);
+    sb += (float)(p.w & 255u);
+}
+
+// Search + sums for window radius W (block-uniform: the largest radius any core pixel of the tile needs).
+// Looking further than a pixel's own radius is harmless: an equal index anywhere in the tile IS the same voxel.
+template <int W>
+__device__ __forceinline__ void win_heads(const uint32_t* s_key, const uint4* s_pt, int wt, uint32_t (&hk)[4], uint4 (&hc)[4],
+                                          uint32_t& nh)
+{
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 4 * k;
+        const int e0 = (r + wt) * kWinRS + (c + wt);
+        const uint32_t key0 = s_key[e0];
+        // any earlier pixel (row-major) with the same index?  independent LDS reads at constant offsets
+        bool before = false;
+#pragma unroll
+        for (int dx = 1; dx <= W; ++dx) before |= s_key[e0 - dx] == key0;
+#pragma unroll
+        for (int dy = 1; dy <= W; ++dy) {
+#pragma unroll
+            for (int dx = -W; dx <= W; ++dx) before |= s_key[e0 - dy * kWinRS + dx] == key0;
+        }
+        const bool head = key0 != kNoKey && !before;
+        if (__ballot(head) == 0ull) continue;  // wave-uniform
+        if (head) {
+            // the voxel's pixels in row-major order: strictly sequential fp32 sums, like the sort-based path
+            const uint4* pt0 = s_pt + (r * kWinRS + (c + wt));  // point rows start at the tile's first row
+            float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
+            uint32_t np = 1;
+            win_add(pt0[0], sx, sy, sz, sr, sg, sb);
+            if (W > 0) {
+                uint32_t mk = 0;
+#pragma unroll
+                for (int dx = 1; dx <= W; ++dx) mk |= (s_key[e0 + dx] == key0 ? 1u : 0u) << (dx - 1);
+                while (mk) {
+                    const int dx = __ffs(mk);
+                    mk &= mk - 1;
+                    win_add(pt0[dx], sx, sy, sz, sr, sg, sb);
+                    ++np;
+                }
+#pragma unroll
+                for (int dy = 1; dy <= W; ++dy) {
+                    mk = 0;
+#pragma unroll
+                    for (int dx = -W; dx <= W; ++dx) mk |= (s_key[e0 + dy * kWinRS + dx] == key0 ? 1u : 0u) << (dx + W);
+                    while (mk) {
+                        const int bx = __ffs(mk) - 1 - W;
+                        mk &= mk - 1;
+                        win_add(pt0[dy * kWinRS + bx], sx, sy, sz, sr, sg, sb);
+                        ++np;
+                    }
+                }
+            }
+            const float nf = (float)np;
+            const float sa = 0.f;  // alpha bytes are 0 (pose_functions.cpp:1120)
+            const uint32_t rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) | ((uint32_t)(sg / nf) << 8) |
+                                  (uint32_t)(sb / nf);
+            const uint4 cv = make_uint4(__float_as_uint(sx / nf), __float_as_uint(sy / nf), __float_as_uint(sz / nf - 0.0f), rgba);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+                if (nh == (uint32_t)sl) {
+                    hk[sl] = key0;
+                    hc[sl] = cv;
+                }
+            ++nh;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_window_group(ReprojectArgs a, const float* __restrict__ wbase,
+                                                      const float* __restrict__ win_c, int tiles_x,
+                                                      const VoxelGeom* __restrict__ geom,
+                                                      const VoxelGeom* __restrict__ geom_gen, int64_t cap,
+                                                      uint32_t* __restrict__ keys_out, o3dr_point* __restrict__ cent_out,
+                                                      uint32_t* __restrict__ n_heads)
+{
+    __shared__ uint4 s_pt[kWinPtRows * kWinRS];    // world point + (R << 16 | G << 8 | B) of the tile and lower halo
+    __shared__ uint32_t s_key[kWinRows * kWinRS];  // voxel index of every region pixel (kNoKey: outside / invalid)
+    __shared__ double lut_alpha[256];
+    __shared__ float lut_z[256];
+    __shared__ float s_bu[256], s_bv[256];
+    __shared__ double s_xt[kWinRS], s_yt[kWinRows];  // Q0*x + Q3 per region column, Q5*y + Q7 per region row
+    __shared__ uint32_t scan_lds[5];
+    __shared__ uint32_t base_lds;
+    __shared__ int wt_lds[4];
+    const int f = blockIdx.y;
+    const VoxelGeom g = geom[f];
+    if (g.n == 0 || geom_gen[f].n != 0) return;  // empty, or left to the sort-based path by k_window_plan
+    const int ty0 = ((int)blockIdx.x / tiles_x) * kWinTY, tx0 = ((int)blockIdx.x % tiles_x) * kWinTX;
+    const uint8_t* disp = a.disp + (int64_t)f * a.disp_fstride;
+    const uint8_t* bgr = a.bgr + (int64_t)f * a.bgr_fstride;
+    // ---- radius this tile needs: the largest one over its own (core) pixels
+    {
+        const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+        const int rx = tx0 + c;
+        uint32_t dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ry = ty0 + r0 + 4 * k;
+            dv[k] = (ry < a.Ny && rx < a.Nx) ? disp[(int64_t)(a.bb + ry * a.jump) * a.disp_pitch + (a.cs + rx * a.jump)] : 0u;
+        }
+        s_bu[threadIdx.x] = wbase[threadIdx.x];
+        s_bv[threadIdx.x] = wbase[256 + threadIdx.x];
+        lut_alpha[threadIdx.x] = a.lut[threadIdx.x].alpha;
+        lut_z[threadIdx.x] = a.lut[threadIdx.x].z;
+        // the same fp64 operations as the per-pixel form (Q0 * x + Q3, then * 1/w), shared by a column / a row
+        if (threadIdx.x < kWinRS)
+            s_xt[threadIdx.x] = a.Q[0] * (double)(a.cs + (tx0 - kWinHalo + (int)threadIdx.x) * a.jump) + a.Q[3];
+        else if (threadIdx.x < kWinRS + kWinRows)
+            s_yt[threadIdx.x - kWinRS] = a.Q[5] * (double)(a.bb + (ty0 - kWinHalo + (int)threadIdx.x - kWinRS) * a.jump) + a.Q[7];
+        __syncthreads();
+        const float cu = win_c[2 * f], cv = win_c[2 * f + 1];
+        int wmax = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ry = ty0 + r0 + 4 * k;
+            if (ry < a.Ny && rx < a.Nx && (double)dv[k] > a.min_disp) {
+                const float fu = cu * s_bu[dv[k]], fv = cv * s_bv[dv[k]];
+                wmax = max(wmax, max((int)(fu + fu * 1e-6f), (int)(fv + fv * 1e-6f)));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+        if ((threadIdx.x & 63) == 0) wt_lds[threadIdx.x >> 6] = wmax;
+    }
+    __syncthreads();
+    const int wt = min(max(max(wt_lds[0], wt_lds[1]), max(wt_lds[2], wt_lds[3])), kWinHalo);
+    if (wt < 0) return;  // no valid pixel in the tile (block-uniform)
+    float m[12];
+    const float* T = a.poses + 16 * (int64_t)f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = T[i];
+    // ---- stage the region (tile + halo of wt): voxel index and point of every pixel.
+    //      All loads of a lane's (up to kWinStage) pixels are issued before any is used: one memory round trip.
+    const int RXt = kWinTX + 2 * wt, RYt = kWinTY + 2 * wt;
+    const int n_region = RXt * RYt;
+    {
+        uint32_t dv[kWinStage], col[kWinStage];
+        int ey[kWinStage], ex[kWinStage];
+        bool in[kWinStage];
+        const bool wide = a.bb >= 1;  // 4-byte colour loads may touch the first byte of the next pixel: needs a margin
+#pragma unroll
+        for (int it = 0; it < kWinStage; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            ey[it] = i / RXt;
+            ex[it] = i - ey[it] * RXt;
+            const int ry = ty0 - wt + ey[it], rx = tx0 - wt + ex[it];
+            in[it] = i < n_region && ry >= 0 && ry < a.Ny && rx >= 0 && rx < a.Nx;
+            dv[it] = col[it] = 0u;
+            if (in[it]) {
+                const int y = a.bb + ry * a.jump, x = a.cs + rx * a.jump;
+                const uint8_t* px = bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
+                dv[it] = disp[(int64_t)y * a.disp_pitch + x];
+                if (wide) {
+                    uint32_t v;
+                    __builtin_memcpy(&v, px, 4);  // unaligned dword load: B | G << 8 | R << 16 | (next B) << 24
+                    col[it] = v & 0xffffffu;
+                } else
+                    col[it] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kWinStage; ++it) {
+            if (threadIdx.x + 256 * it < n_region) {
+                uint32_t key = kNoKey;
+                if (in[it] && (double)dv[it] > a.min_disp) {
+                    const double al = lut_alpha[dv[it]];
+                    const float X = (float)(s_xt[ex[it] + kWinHalo - wt] * al + 0.0);
+                    const float Y = (float)(s_yt[ey[it] + kWinHalo - wt] * al + 0.0);
+                    const float Z = lut_z[dv[it]];
+                    const float wx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+                    const float wy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+                    const float wz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+                    const int32_t i0 = (int32_t)floorf(wx * g.inv[0]) - g.min_b[0];
+                    const int32_t i1 = (int32_t)floorf(wy * g.inv[1]) - g.min_b[1];
+                    const int32_t i2 = (int32_t)floorf(wz * g.inv[2]) - g.min_b[2];
+                    key = (uint32_t)i0 + (uint32_t)i1 * g.mul1 + (uint32_t)i2 * g.mul2;
+                    if (ey[it] >= wt)
+                        s_pt[(ey[it] - wt) * kWinRS + ex[it]] = make_uint4(__float_as_uint(wx), __float_as_uint(wy),
+                                                                           __float_as_uint(wz), col[it]);
+                }
+                s_key[ey[it] * kWinRS + ex[it]] = key;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- heads (lowest row-major pixel of a voxel) add up their voxel
+    uint32_t hk[4];
+    uint4 hc[4];
+    uint32_t nh = 0;
+    switch (wt) {
+        case 0: win_heads<0>(s_key, s_pt, wt, hk, hc, nh); break;
+        case 1: win_heads<1>(s_key, s_pt, wt, hk, hc, nh); break;
+        case 2: win_heads<2>(s_key, s_pt, wt, hk, hc, nh); break;
+        case 3: win_heads<3>(s_key, s_pt, wt, hk, hc, nh); break;
+        case 4: win_heads<4>(s_key, s_pt, wt, hk, hc, nh); break;
+        case 5: win_heads<5>(s_key, s_pt, wt, hk, hc, nh); break;
+        case 6: win_heads<6>(s_key, s_pt, wt, hk, hc, nh); break;
+        case 7: win_heads<7>(s_key, s_pt, wt, hk, hc, nh); break;
+        default: win_heads<8>(s_key, s_pt, wt, hk, hc, nh); break;
+    }
+    // ---- append the tile's voxels to the frame's record list (any order: the indices are unique and get sorted)
+    uint32_t total;
+    const uint32_t pos = block_excl_scan_u32<4>(nh, scan_lds, total);
+    if (threadIdx.x == 0) base_lds = total ? atomicAdd(&n_heads[f], total) : 0u;
+    __syncthreads();
+    const int64_t o = (int64_t)f * cap + base_lds + pos;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((uint32_t)k < nh) {
+            keys_out[o + k] = hk[k];
+            reinterpret_cast<uint4*>(cent_out)[o + k] = hc[k];
+        }
+    }
+}
+
+// which frames of the batch take the window path, and with which window.  Two pixels whose computed world points
+// share a voxel differ by less than leaf (+ 2 rounding errors) along every world axis, hence along camera X by at
+// most sum_i |R^-1[0][i]| times that.  For a pose within 1 % of orthonormal the sum is below |R00|+|R10|+|R20| + 0.031;
+// with the rounding budget (err <= 0.025 leaf, checked here) the bound is (1.06 L1 + 0.05) leaf =: c_u leaf, same for Y.
+// The host table holds leaf / (pixel footprint at disparity d); the radius is floor(c * table[d]).
+// geom_gen is what the sort-based kernels see (n = 0: nothing to do), n_heads the record counters of the window kernel.
+__global__ void k_window_plan(const VoxelGeom* __restrict__ geom, const float* __restrict__ poses, int frames, float rho_max,
+                              float err_budget, VoxelGeom* __restrict__ geom_gen, uint32_t* __restrict__ n_heads,
+                              float* __restrict__ win_c)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    VoxelGeom g = geom[f];
+    const float* T = poses + 16 * (int64_t)f;
+    // || R^T R - I ||_F <= 0.01
+    float dev = 0.f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const float d = T[i] * T[j] + T[4 + i] * T[4 + j] + T[8 + i] * T[8 + j] - (i == j ? 1.f : 0.f);
+            dev += d * d;
+        }
+    const float tn = sqrtf(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
+    // |error of a computed world coordinate| <= 8 half-ulps of (range + |t|): 3 products, 3 sums, rounded inputs
+    const float err = 4.76837158e-7f * (rho_max + tn);  // 2^-21
+    const float cu = 1.06f * (fabsf(T[0]) + fabsf(T[4]) + fabsf(T[8])) + 0.05f;
+    const float cv = 1.06f * (fabsf(T[1]) + fabsf(T[5]) + fabsf(T[9])) + 0.05f;
+    // NaN poses fail the comparisons; kWinCMax is the factor the host sized the halo and the depth-level test with
+    const bool window = g.n != 0 && !g.overflow && dev <= 1e-4f && err <= err_budget && cu <= kWinCMax && cv <= kWinCMax;
+    if (window) g.n = 0;
+    geom_gen[f] = g;
+    n_heads[f] = 0;
+    win_c[2 * f] = cu;
+    win_c[2 * f + 1] = cv;
+}
+// geometry the sort sees: window frames sort their voxel records (buffer 1 first; bit 1 of buf0 marks them)
+__global__ void k_window_sort_geom(const VoxelGeom* __restrict__ geom, const VoxelGeom* __restrict__ geom_gen,
+                                   const uint32_t* __restrict__ n_heads, int frames, VoxelGeom* __restrict__ geom_sort)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    VoxelGeom g = geom[f];
+    if (g.n != 0 && geom_gen[f].n == 0) {
+        g.n = n_heads[f];
+        g.buf0 = 3;
+    }
+    geom_sort[f] = g;
+}
+
+// sorted voxel records of the window frames -> output
+__global__ __launch_bounds__(kPtThreads) void k_gather_heads(const o3dr_point* __restrict__ pts, int64_t cap,
+                                                             const uint32_t* __restrict__ ids0,
+                                                             const uint32_t* __restrict__ ids1,
+                                                             const VoxelGeom* __restrict__ geom_runs,
+                                                             const uint32_t* __restrict__ n_out,
+                                                             const uint64_t* __restrict__ out_off,
+                                                             o3dr_point* __restrict__ out_base)
+{
+    const int f = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
+    const VoxelGeom g = geom_runs[f];
+    if (!(g.buf0 & 2u) || j >= n_out[f]) return;
+    const uint4* src = reinterpret_cast<const uint4*>(pts + (int64_t)f * cap);
+    uint4* dst = reinterpret_cast<uint4*>(out_base + out_off[f]);
+    dst[j] = src[(sorted_buf(g, ids0, ids1) + (int64_t)f * cap)[j]];
+}
+
+// =================================================================================================
 // K2a — PCL VoxelGrid geometry and per-point linear index
 //   [PCL 1.8 filters/impl/voxel_grid.hpp applyFilter; called from pose_functions.cpp:1689-1700]
 // =================================================================================================
@@ -541,6 +931,7 @@ __global__ __launch_bounds__(256) void k_voxel_geom(const float* __restrict__ mm
     g.passes = 0;
     g.bpp = 8;
     g.buf0 = 0;
+    g.val_bits = 0;
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
         g.inv[a] = 1.0f / leaf[a];  // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
@@ -771,7 +1162,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
                                                                 const uint32_t* __restrict__ digit_start,
                                                                 uint64_t* __restrict__ lb_state,
                                                                 uint32_t* __restrict__ tickets, uint32_t epoch,
-                                                                uint32_t* __restrict__ error_flag)
+                                                                uint32_t* __restrict__ error_flag,
+                                                                const uint32_t* __restrict__ run_start)
 {
     __shared__ uint32_t wave_cnt[kSortWaves * kMaxRadix];  // per-wave digit counts -> exclusive wave prefixes
     __shared__ uint32_t local_base[kMaxRadix];             // start of each digit inside the tile's sorted order
@@ -813,6 +1205,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(uint32_t* __rest
         const bool ok = i < n;
         key[r] = ok ? kin[i] : 0xffffffffu;
         val[r] = (pass == 0) ? (uint32_t)i : (ok ? vin[i] : 0u);
+        if (pass == 0 && g.val_bits != 0u && ok) {  // records are runs: payload = (first point, length)
+            const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
+            val[r] = run_pack(rs[i], rs[i + 1], g.val_bits);
+        }
     }
     volatile uint32_t* wc = wave_cnt + w * kMaxRadix;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -951,7 +1347,8 @@ constexpr int kCntStride = 17;  // dwords per digit row: 16 lane-quads + 1 pad (
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lane(uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
                                                                      uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
                                                                      int64_t cap, const VoxelGeom* __restrict__ geom, int pass,
-                                                                     int n_tiles, const uint32_t* __restrict__ hist_scanned)
+                                                                     int n_tiles, const uint32_t* __restrict__ hist_scanned,
+                                                                     const uint32_t* __restrict__ run_start)
 {
     constexpr int kCntWords = kMaxRadix * kCntStride;  // per wave
     constexpr int kRankWords = kSortWaves * kCntWords;
@@ -1007,8 +1404,19 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lane(uint32_t* _
         }
     }
     if (pass == 0) {
+        if (g.val_bits != 0u) {  // records are runs: payload = (first point, length) from the run starts
+            const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
+            uint32_t nxt = lbase < (int64_t)n ? rs[lbase] : 0u;
 #pragma unroll
-        for (int r = 0; r < kSortRounds; ++r) val[r] = (uint32_t)(lbase + r);
+            for (int r = 0; r < kSortRounds; ++r) {
+                const uint32_t first = nxt;
+                nxt = (lbase + r < (int64_t)n) ? rs[lbase + r + 1] : 0u;
+                val[r] = (lbase + r < (int64_t)n) ? run_pack(first, nxt, g.val_bits) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kSortRounds; ++r) val[r] = (uint32_t)(lbase + r);
+        }
     }
 
     // ---- A. own-lane ranks
@@ -1119,13 +1527,15 @@ __global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ 
     if (g.overflow) return;
     const uint32_t n = g.n;
     const uint32_t* k = (buf_sel < 0 ? sorted_buf(g, keys0, keys1) : (buf_sel ? keys1 : keys0)) + (int64_t)f * cap;
+    // forming runs of points (buf_sel 0): also cut where the packed length would overflow
+    const uint32_t split = buf_sel == 0 ? run_split_mask(run_start_bits(n)) : 0xffffffffu;
     uint32_t c = 0;
     const int64_t base = (int64_t)tile * kSegTile;
     if (base < n) {
 #pragma unroll
         for (int j = 0; j < kSegTile / 256; ++j) {
             const int64_t i = base + j * 256 + threadIdx.x;
-            if (i < n) c += (i == 0 || k[i] != k[i - 1]) ? 1u : 0u;
+            if (i < n) c += (((uint32_t)i & split) == 0u || k[i] != k[i - 1]) ? 1u : 0u;
         }
     }
     c = wave_sum_u32(c);
@@ -1152,10 +1562,11 @@ __global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__
     uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
     if (tile == 0 && threadIdx.x == 0) ss[n_vox[f]] = n;  // sentinel: end of the last run
     uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
+    const uint32_t split = buf_sel == 0 ? run_split_mask(run_start_bits(n)) : 0xffffffffu;
     // 4 sub-rows of 256 consecutive records keep (sub-row, lane) order = sorted order
     for (int j = 0; j < kSegTile / 256; ++j) {
         const int64_t i = base + j * 256 + threadIdx.x;
-        const bool head = (i < n) && (i == 0 || k[i] != k[i - 1]);
+        const bool head = (i < n) && (((uint32_t)i & split) == 0u || k[i] != k[i - 1]);
         uint32_t total;
         const uint32_t pos = block_excl_scan_u32<4>(head ? 1u : 0u, scan_lds, total);
         if (head) {
@@ -1224,8 +1635,8 @@ __global__ __launch_bounds__(256) void k_frame_offsets(const VoxelGeom* __restri
                                                        const VoxelGeom* __restrict__ sort_geom)
 {
     __shared__ uint32_t scan_lds[5];
-    __shared__ unsigned long long acc[4];  // record-passes, points in, points out, status
-    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+    __shared__ unsigned long long acc[6];  // record-passes, points in, points out, status, window frames, records
+    if (threadIdx.x < 6) acc[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = cc->count;
     uint64_t carry = 0;
@@ -1241,7 +1652,12 @@ __global__ __launch_bounds__(256) void k_frame_offsets(const VoxelGeom* __restri
                 atomicOr(&acc[3], (unsigned long long)O3DR_STATUS_VOXEL_OVERFLOW);
             } else {
                 m = n_keep ? n_keep[f] : n_vox[f];
+                if (sort_geom[f].buf0 & 2u) {  // window frame: one record per voxel
+                    m = sort_geom[f].n;
+                    atomicAdd(&acc[4], 1ull);
+                }
                 atomicAdd(&acc[0], (unsigned long long)sort_geom[f].n * g.passes);  // records actually sorted
+                atomicAdd(&acc[5], (unsigned long long)sort_geom[f].n);
                 atomicAdd(&acc[1], (unsigned long long)g.n);
                 atomicAdd(&acc[2], (unsigned long long)m);
             }
@@ -1262,6 +1678,8 @@ __global__ __launch_bounds__(256) void k_frame_offsets(const VoxelGeom* __restri
             stats->sort_record_passes += acc[0];
             stats->voxel_points_in += acc[1];
             stats->voxel_points_out += acc[2];
+            stats->window_frames += acc[4];
+            stats->sort_records += acc[5];
         }
     }
 }
@@ -1286,6 +1704,7 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
         return;
     }
     const VoxelGeom g = geom[f];
+    if (g.n == 0) return;  // frame taken by the pixel-window path (k_gather_heads writes it)
     if (g.overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
         uint4 v = src[o];
         v.z = __float_as_uint((__uint_as_float(v.z) + z_offset) - z_offset);
@@ -1340,6 +1759,7 @@ __global__ void k_run_geom(const VoxelGeom* __restrict__ geom, const uint32_t* _
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= frames) return;
     VoxelGeom g = geom[f];
+    g.val_bits = run_start_bits(g.n);  // payload = (first point, length) of the run
     g.n = g.overflow ? 0u : n_runs[f];
     g.buf0 = 1;  // the run keys are gathered into buffer 1
     geom_runs[f] = g;
@@ -1359,9 +1779,9 @@ __global__ __launch_bounds__(256) void k_run_lengths(const uint32_t* __restrict_
         out[j] = 0;
         return;
     }
-    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
-    const uint32_t r = (sorted_buf(g, ids0, ids1) + (int64_t)f * cap)[j];
-    out[j] = rs[r + 1] - rs[r];
+    uint32_t first, len;
+    run_unpack((sorted_buf(g, ids0, ids1) + (int64_t)f * cap)[j], g.val_bits, first, len);
+    out[j] = len;
 }
 __global__ __launch_bounds__(256) void k_keep_count_runs(const uint32_t* __restrict__ seg_start,
                                                          const uint32_t* __restrict__ len_pref, int64_t cap,
@@ -1442,41 +1862,64 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid_runs(const o3dr_point* 
         return;
     }
     const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
-    const uint32_t* rs = run_start + (int64_t)f * (cap + 1);
-    const uint32_t* rid = sorted_buf(g, ids0, ids1) + (int64_t)f * cap;
+    const uint32_t* rv = sorted_buf(g, ids0, ids1) + (int64_t)f * cap;  // sorted payloads: (first point, length)
     const uint32_t v = keep_idx ? keep_idx[(int64_t)f * cap + o] : (uint32_t)o;
     const uint32_t jb = ss[v], je = ss[v + 1];
+    const uint32_t bits = g.val_bits;
     float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
     uint32_t n_pts = 0;
-    // the sums are strictly sequential; loads run ahead: 4 runs' bounds, then up to 4 points of a run
+    // The sums are strictly sequential; the loads are not: the next 4 payloads and the first 4 points of each of
+    // this group's 4 runs are in flight before the first add (runs are short, a few points each).
+    uint32_t nv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nv[k] = (jb + k < je) ? rv[jb + k] : 0u;
     for (uint32_t j = jb; j < je; j += 4) {
         uint32_t b[4], e[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            b[k] = e[k] = 0;
-            if (j + k < je) {
-                const uint32_t r = rid[j + k];
-                b[k] = rs[r];
-                e[k] = rs[r + 1];
-            }
+            uint32_t first, len;
+            run_unpack(nv[k], bits, first, len);
+            b[k] = first;
+            e[k] = (j + k < je) ? first + len : first;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nv[k] = (j + 4 + k < je) ? rv[j + 4 + k] : 0u;
+        uint4 p[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (b[k] + q < e[k]) p[k][q] = src[b[k] + q];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            for (uint32_t i = b[k]; i < e[k]; i += 4) {
-                uint4 p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (b[k] + q < e[k]) {
+                    sx += __uint_as_float(p[k][q].x);
+                    sy += __uint_as_float(p[k][q].y);
+                    sz += __uint_as_float(p[k][q].z) + z_offset;
+                    sr += (float)((p[k][q].w >> 16) & 255u);
+                    sg += (float)((p[k][q].w >> 8) & 255u);
+                    sb += (float)(p[k][q].w & 255u);
+                    sa += (float)(p[k][q].w >> 24);
+                }
+            }
+            for (uint32_t i = b[k] + 4; i < e[k]; i += 4) {  // the rest of a long run
+                uint4 t[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (i + q < e[k]) p[q] = src[i + q];
+                    if (i + q < e[k]) t[q] = src[i + q];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (i + q < e[k]) {
-                        sx += __uint_as_float(p[q].x);
-                        sy += __uint_as_float(p[q].y);
-                        sz += __uint_as_float(p[q].z) + z_offset;
-                        sr += (float)((p[q].w >> 16) & 255u);
-                        sg += (float)((p[q].w >> 8) & 255u);
-                        sb += (float)(p[q].w & 255u);
-                        sa += (float)(p[q].w >> 24);
+                        sx += __uint_as_float(t[q].x);
+                        sy += __uint_as_float(t[q].y);
+                        sz += __uint_as_float(t[q].z) + z_offset;
+                        sr += (float)((t[q].w >> 16) & 255u);
+                        sg += (float)((t[q].w >> 8) & 255u);
+                        sb += (float)(t[q].w & 255u);
+                        sa += (float)(t[q].w >> 24);
                     }
                 }
             }
@@ -1639,6 +2082,7 @@ __global__ __launch_bounds__(256) void k_sor_plan(const float* __restrict__ mm, 
     v.mul1 = v.mul2 = 1;
     v.n = g.n;
     v.buf0 = 0;
+    v.val_bits = 0;
     v.overflow = g.active ? 0u : 1u;  // inactive: every sort kernel returns at once
     const uint64_t cells = (uint64_t)gx * (uint64_t)gy;
     uint32_t nbits = cells > 1 ? 64u - (uint32_t)__clzll((long long)(cells - 1)) : 1u;
@@ -1927,7 +2371,21 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     }
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
-        k_reproject_emit<<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
+        k_reproject_emit<<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr);
+    }
+}
+
+void launch_frame_bbox(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, uint32_t* tile_cnt,
+                       const uint32_t* n_kp, uint32_t* n_valid, float* mm, uint32_t* scan_partial)
+{
+    const dim3 grid(a.n_tiles, frames);
+    {
+        ProfScope ps(pf, O3DR_K_COUNT, s);
+        k_frame_bbox<<<grid, kEmitThreads, 0, s>>>(a, tile_cnt, mm);
+    }
+    {
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        launch_scan(s, tile_cnt, a.n_tiles, a.n_tiles, frames, n_valid, n_kp, scan_partial);
     }
 }
 
@@ -1968,7 +2426,34 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     uint32_t* n_keep = nullptr;
     // run compression: whole-cloud calls only, and not together with the look-back variant
     const bool use_runs = v.use_runs && !ws.single_pass && !v.passthrough;
-    const VoxelGeom* sort_geom = use_runs ? ws.geom_runs : ws.geom;  // what the sort and the run/cell kernels count
+    const WindowPlan* w = (v.window && !use_runs && !ws.single_pass && !v.passthrough && cap > 0) ? v.window : nullptr;
+    // what the sort and the run/cell kernels count (runs / voxel records of window frames / points)
+    const VoxelGeom* sort_geom = (use_runs || w) ? ws.geom_runs : ws.geom;
+    // what the per-point kernels of the sort-based path see: frames on the window path have n = 0 there
+    const VoxelGeom* gen_geom = w ? ws.geom_gen : ws.geom;
+    const VoxelGeom* seg_geom = w ? ws.geom_gen : sort_geom;
+    if (w) {
+        {
+            ProfScope ps(pf, O3DR_K_OTHER, s);
+            k_window_plan<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, w->a.poses, F, w->rho_max, w->err_budget, ws.geom_gen, ws.n_runs,
+                                                       ws.win_c);
+        }
+        {
+            ProfScope ps(pf, O3DR_K_REPROJECT, s);
+            k_reproject_emit<<<dim3(w->a.n_tiles, F), kEmitThreads, 0, s>>>(w->a, const_cast<o3dr_point*>(v.in), ws.tile_cnt,
+                                                                             w->n_kp, ws.mm, ws.geom_gen);
+        }
+        {
+            ProfScope ps(pf, O3DR_K_WINDOW, s);
+            const int tiles_x = cdiv64(w->a.Nx, kWinTX), tiles_y = cdiv64(w->a.Ny, kWinTY);
+            k_window_group<<<dim3(tiles_x * tiles_y, F), 256, 0, s>>>(w->a, w->wbase, ws.win_c, tiles_x, ws.geom, ws.geom_gen, cap,
+                                                                      ws.keys[1], const_cast<o3dr_point*>(v.in), ws.n_runs);
+        }
+        {
+            ProfScope ps(pf, O3DR_K_OTHER, s);
+            k_window_sort_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.geom_gen, ws.n_runs, F, ws.geom_runs);
+        }
+    }
     if (!v.passthrough && cap > 0) {
         const dim3 grid(n_sort_tiles, F);
         if (ws.single_pass) {
@@ -1995,12 +2480,12 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
                 k_radix_scatter<true><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
                                                                    ws.geom, pass, n_sort_tiles, nullptr, ws.digit_start,
-                                                                   ws.lb_state, ws.tickets, ++ws.epoch, ws.error_flag);
+                                                                   ws.lb_state, ws.tickets, ++ws.epoch, ws.error_flag, nullptr);
             }
         } else {
             {
                 ProfScope ps(pf, O3DR_K_KEYGEN, s);
-                k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, ws.geom,
+                k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, gen_geom,
                                                                                         v.z_offset, cap, ws.keys[0]);
             }
             if (use_runs) {
@@ -2039,17 +2524,17 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                     if (ws.scatter_ballot)
                         k_radix_scatter<false><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
                                                                             sort_geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
-                                                                            nullptr, 0u, nullptr);
+                                                                            nullptr, 0u, nullptr, ws.run_start);
                     else
                         k_radix_scatter_lane<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                          sort_geom, pass, n_sort_tiles, ws.hist);
+                                                                          sort_geom, pass, n_sort_tiles, ws.hist, ws.run_start);
                 }
             }
         }
         const dim3 sgrid(n_seg_tiles, F);
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, -1);
+            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, seg_geom, n_seg_tiles, ws.seg_cnt, -1);
         }
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -2057,7 +2542,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         }
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
+            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, seg_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
                                               ws.seg_start, -1, nullptr);
         }
         if (v.min_points > 1) {
@@ -2072,7 +2557,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                     k_keep_count_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
                                                            n_seg_tiles, ws.seg_cnt);
                 } else
-                    k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
+                    k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, gen_geom, ws.n_vox, v.min_points, n_seg_tiles,
                                                       ws.seg_cnt);
             }
             {
@@ -2085,7 +2570,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                     k_keep_write_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
                                                            n_seg_tiles, ws.seg_cnt, ws.keep_idx);
                 else
-                    k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, ws.geom, ws.n_vox, v.min_points, n_seg_tiles,
+                    k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, gen_geom, ws.n_vox, v.min_points, n_seg_tiles,
                                                       ws.seg_cnt, ws.keep_idx);
             }
             n_keep = ws.n_out;
@@ -2105,8 +2590,11 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         else
             k_centroid<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start,
-                (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, ws.geom, ws.n_out, ws.out_off, v.z_offset,
+                (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, gen_geom, ws.n_out, ws.out_off, v.z_offset,
                 v.passthrough, v.out_base);
+        if (w)
+            k_gather_heads<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(v.in, cap, ws.vals[0], ws.vals[1], ws.geom_runs,
+                                                                                 ws.n_out, ws.out_off, v.out_base);
     }
 }
 
@@ -2134,7 +2622,7 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
     launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, 0, n_sort_tiles);
     k_radix_scatter<false><<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
                                                                          ws.geom, 0, n_sort_tiles, ws.hist, nullptr, nullptr, nullptr,
-                                                                         0u, nullptr);
+                                                                         0u, nullptr, nullptr);
     k_gather_points<<<cdiv64(cap, 256), 256, 0, s>>>(v.in, ws.vals[1], ws.geom, out);
     k_part_counts<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.keys[1], ws.geom, n_parts, counts_dev, overflow_dev);
 }
@@ -2158,7 +2646,7 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
         launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
         k_radix_scatter<false><<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
                                                                              ws.geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
-                                                                             nullptr, 0u, nullptr);
+                                                                             nullptr, 0u, nullptr, nullptr);
     }
     k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
                                                      ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);

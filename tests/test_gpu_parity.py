@@ -485,7 +485,7 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"O3DR_SCATTER": "ballot"}, {"O3DR_SORT": "lookback"}, {"O3DR_RUNS": "0"},
-                                 {"O3DR_NO_QLUT": "1"}, {"O3DR_BATCH_FRAMES": "3"}])
+                                 {"O3DR_NO_QLUT": "1"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_WINDOW": "1"}])
 def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     """the A/B variants kept behind environment switches (ballot-matching scatter, look-back single-pass
     sort, per-point instead of per-run merge, general Q product, small launch groups) give the same bits"""
@@ -507,6 +507,64 @@ def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     assert_points_equal(big, rbig, f"cloud_big {env}")
     assert_points_equal(small, rsmall, f"cloud_small {env}")
     assert_points_equal(vg, orc.voxel_grid(pts, (0.02, 0.03, 0.04), 0)[0], f"voxel grid {env}")
+
+
+def test_A7_window_path_mixed_batch(orc, monkeypatch):
+    """pixel-window voxel grouping (opt-in, O3DR_WINDOW=1): a batch whose frames take it (rigid pose) next to frames that must not
+    (scaled or sheared pose, translation too far for the fp32 margin, overflow guard) and an empty frame;
+    disparities over the whole valid range so every window radius is exercised"""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    monkeypatch.setenv("O3DR_WINDOW", "1")
+    Qs = synth.camera_Q()
+    F = 7
+    disp, bgr = synth.make_frames(300, F, invalid_frac=0.03)
+    rng = np.random.default_rng(5)
+    # frame 1: slanted plane through every disparity level 65..255, noisy; frame 2: blocks of constant disparity
+    yy, xx = np.mgrid[0:720, 0:1280]
+    disp[1] = np.clip(60 + (xx * 200) // 1280 + rng.integers(-2, 3, (720, 1280)), 0, 255).astype(np.uint8)
+    disp[2] = (66 + 27 * ((xx // 97 + yy // 61) % 8)).astype(np.uint8)
+    disp[3][:] = 255
+    disp[5][:] = 0  # nothing valid
+    poses = synth.make_poses(300, F)
+    poses[4, :3, :3] *= 1.5                 # not rigid
+    poses[6, :3, 3] += np.float32(9000.0)   # rounding of world coordinates no longer negligible
+    with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=1, voxel_size=0.05)) as c:
+        c.profileReset()
+        c.accumulateFrames(disp, bgr, poses)
+        big = c.cloudBigRead()
+        n, st = c.cloudBigSize()
+        stats = c.profileStats4()
+    rbig = np.concatenate([orc.create_and_transform_pt_cloud(disp[i], bgr[i], Qs, poses[i], 0.05, jump_pixels=1)[0]
+                           for i in range(F)])
+    assert stats[3] == 4, stats  # frames 0-3 on the window path; 4 and 6 on the sort path; 5 empty
+    assert st == 0 and n == len(rbig)
+    assert_points_equal(big, rbig, "cloud_big (window path, mixed batch)")
+
+
+@pytest.mark.parametrize("jump,vs,rows,cols", [(1, 0.05, 720, 1280), (2, 0.05, 720, 1280), (3, 0.08, 333, 517), (2, 0.1, 97, 211)])
+def test_A7_window_path_equals_sort_path(orc, monkeypatch, jump, vs, rows, cols):
+    """same batch with and without the window path: identical bits (and both equal the oracle)"""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    Qs = synth.camera_Q(rows, cols)
+    F = 4
+    disp, bgr = synth.make_frames(40, F, rows, cols, invalid_frac=0.05)
+    rng = np.random.default_rng(jump)
+    disp[1] = rng.integers(60, 256, (rows, cols)).astype(np.uint8)  # every pixel its own depth level
+    poses = synth.make_poses(40, F)
+    out = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("O3DR_WINDOW", env)
+        with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=jump, voxel_size=vs)) as c:
+            c.profileReset()
+            c.accumulateFrames(disp, bgr, poses)
+            out.append((c.cloudBigRead(), c.profileStats4()[3]))
+    assert out[0][1] > 0 and out[1][1] == 0
+    assert_points_equal(out[0][0], out[1][0], "window path vs sort path")
+    rbig = np.concatenate([orc.create_and_transform_pt_cloud(disp[i], bgr[i], Qs, poses[i], vs, jump_pixels=jump)[0]
+                           for i in range(F)])
+    assert_points_equal(out[0][0], rbig, "window path vs oracle")
 
 
 def test_A1_row_pitch_larger_than_width(ctx, orc, Q, frame_1249):
