@@ -76,6 +76,9 @@ typedef struct o3dr_params {
     int32_t  sor_enable;           /* statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686:
                                       mean_k 50, 1 sigma, active iff !combined && jump_pixels > 0).  0 = off (the
                                       measured GPU configs); 1 = on, as in the reference */
+    int32_t  blur_kernel;          /* pose.h:98 blur_kernel = 1; > 1: the disparity image goes through
+                                      cv::bilateralFilter(d = blur_kernel, sigmaColor = 2*blur_kernel,
+                                      sigmaSpace = blur_kernel/2 (integer division)) first, pose_functions.cpp:1040-1047 */
 } o3dr_params;
 
 typedef struct o3dr_ctx o3dr_ctx; /* opaque */
@@ -114,6 +117,21 @@ int o3dr_create_single_img_pt_cloud(o3dr_ctx* ctx,
                                     int32_t mem);
 /* number of grid-pass candidates for the context's current params: Ny*Nx of SURVEY section 8 */
 int64_t o3dr_max_points(o3dr_ctx* ctx, int32_t rows, int32_t cols);
+
+/* ---- disparity pre-passes -------------------------------------------------------------------
+ * cv::bilateralFilter on a CV_8UC1 image — replaces the call at pose_functions.cpp:1044 (OpenCV 3.1
+ * bilateralFilter_8u, BORDER_DEFAULT, fp32 sums grouped as an x86-64 build groups them).  d <= 0 derives the
+ * radius from sigma_space like OpenCV; radius (d/2) above 64 is O3DR_ERR_INVALID_ARG.  src and dst must not
+ * overlap.  With O3DR_MEM_DEVICE the call is asynchronous on the context's stream.  Runs inside the frame calls
+ * by itself when o3dr_params.blur_kernel > 1. */
+int o3dr_bilateral_filter_u8(o3dr_ctx* ctx, const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
+                             double sigma_color, double sigma_space, uint8_t* dst, int64_t dst_pitch, int32_t mem);
+/* Pose::getVariance(disp, false) of n_frames disparity images (pose_functions.cpp:987-1028; the frame gate of
+ * pose.cpp:187-196 rejects a frame when it exceeds 5), over the ROI set by o3dr_params.  variance_out: n_frames
+ * doubles in HOST memory.  The mean is bit-identical to the reference's; the variance is summed per disparity
+ * level instead of per pixel and agrees to fp64 rounding (within N * 2^-53 relative, N = ROI pixels). */
+int o3dr_disparity_variance(o3dr_ctx* ctx, const uint8_t* disp, int64_t disp_pitch, int64_t disp_frame_stride, int32_t rows,
+                            int32_t cols, int32_t n_frames, double* variance_out, int32_t mem);
 
 /* ---- A2: Pose::transformPtCloud (pose.h:199, pose_functions.cpp:1358-1362) ----------------------
  * out[i].xyz = T * in[i].xyz in fp32, ((m0*x + m1*y) + m2*z) + m3, no fused multiply-add

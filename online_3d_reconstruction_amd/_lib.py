@@ -27,7 +27,7 @@ class O3drError(RuntimeError):
 class ParamsStruct(C.Structure):
     _fields_ = [("min_disparity", C.c_double), ("voxel_size", C.c_double), ("bounding_box", C.c_int32),
                 ("cutout_ratio", C.c_int32), ("jump_pixels", C.c_int32), ("min_points_per_voxel", C.c_uint32),
-                ("dont_downsample", C.c_int32), ("sor_enable", C.c_int32)]
+                ("dont_downsample", C.c_int32), ("sor_enable", C.c_int32), ("blur_kernel", C.c_int32)]
 
 
 def lib_path():
@@ -54,6 +54,8 @@ SYMBOLS = [
     ("o3dr_reproject_transform", C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _pi64, _i32]),
     ("o3dr_voxel_grid", C.c_int, [_vp, _vp, _i64, _vp, _u32, _f, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_statistical_outlier_removal", C.c_int, [_vp, _vp, _i64, _vp, _i64, _pi64, _i32]),
+    ("o3dr_bilateral_filter_u8", C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, C.c_double, C.c_double, _vp, _i64, _i32]),
+    ("o3dr_disparity_variance", C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _i32]),
     ("o3dr_downsample_pt_cloud", C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_create_and_transform_pt_cloud", C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_accumulate_frames", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32]),

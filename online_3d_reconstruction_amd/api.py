@@ -26,11 +26,12 @@ class Params:
     min_points_per_voxel: int = 1
     dont_downsample: bool = False
     sor_enable: bool = False
+    blur_kernel: int = 1
 
     def to_struct(self):
         return L.ParamsStruct(float(self.min_disparity), float(self.voxel_size), int(self.bounding_box),
                               int(self.cutout_ratio), int(self.jump_pixels), int(self.min_points_per_voxel),
-                              int(bool(self.dont_downsample)), int(bool(self.sor_enable)))
+                              int(bool(self.dont_downsample)), int(bool(self.sor_enable)), int(self.blur_kernel))
 
 
 def _is_torch(x):
@@ -197,6 +198,42 @@ class Context:
         L.check(self._lib.o3dr_downsample_pt_cloud(self._h, pi, n_in, int(bool(combinedPtCloud)), po, max(n_in, 1),
                                                   C.byref(n), C.byref(st), mem))
         return (out[: n.value], st.value) if return_status else out[: n.value]
+
+    def bilateralFilter(self, img, d, sigma_color, sigma_space):
+        """cv::bilateralFilter on a u8 image (pose_functions.cpp:1044); numpy in/out or torch CUDA in/out."""
+        if _is_torch(img):
+            import torch
+            assert img.dtype == torch.uint8 and img.dim() == 2 and img.stride(1) == 1
+            out = torch.empty_like(img, memory_format=torch.contiguous_format)
+            L.check(self._lib.o3dr_bilateral_filter_u8(self._h, img.data_ptr(), img.stride(0), img.shape[0], img.shape[1], int(d),
+                                                       float(sigma_color), float(sigma_space), out.data_ptr(), out.stride(0),
+                                                       L.MEM_DEVICE if img.is_cuda else L.MEM_HOST))
+            if img.is_cuda:
+                L.check(self._lib.o3dr_ctx_synchronize(self._h))  # the library's stream is not torch's
+            return out
+        img = np.asarray(img, np.uint8)
+        assert img.ndim == 2 and img.strides[1] == 1
+        out = np.empty(img.shape, np.uint8)
+        L.check(self._lib.o3dr_bilateral_filter_u8(self._h, img.ctypes.data, img.strides[0], img.shape[0], img.shape[1], int(d),
+                                                   float(sigma_color), float(sigma_space), out.ctypes.data, out.strides[0],
+                                                   L.MEM_HOST))
+        return out
+
+    def disparityVariance(self, disp):
+        """Pose::getVariance per frame (pose_functions.cpp:1007-1028) of a [F,H,W] or [H,W] u8 stack -> float64 [F]"""
+        if disp.ndim == 2:
+            disp = disp[None]
+        F, rows, cols = (int(v) for v in disp.shape)
+        if _is_torch(disp):
+            assert disp.stride(2) == 1
+            ptr, mem, fs, pitch = disp.data_ptr(), (L.MEM_DEVICE if disp.is_cuda else L.MEM_HOST), disp.stride(0), disp.stride(1)
+        else:
+            disp = np.asarray(disp, np.uint8)
+            assert disp.strides[2] == 1
+            ptr, mem, fs, pitch = disp.ctypes.data, L.MEM_HOST, disp.strides[0], disp.strides[1]
+        out = np.zeros(F, np.float64)
+        L.check(self._lib.o3dr_disparity_variance(self._h, ptr, pitch, fs, rows, cols, F, out.ctypes.data, mem))
+        return out
 
     def statisticalOutlierRemoval(self, pts):
         """pcl::StatisticalOutlierRemoval, mean_k 50, 1 sigma (pose_functions.cpp:1679-1684)."""

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <vector>
 
 #include "o3dr_device.h"
 #include "o3dr_profile.h"
@@ -64,6 +65,11 @@ struct o3dr_ctx {
     float* win_tab_host = nullptr;  // pinned
     int win_enable = 0;
     bool win_tab_valid = false;
+    // cv::bilateralFilter tables (colour weights | space weights | tile offsets) for the last (d, sigmas) used
+    DevBuf bil_tab, st_blur, st_blur_in, st_hist;
+    int bil_d = 0, bil_radius = 0, bil_maxk = 0;
+    double bil_sc = 0, bil_ss = 0;
+    bool bil_valid = false;
     int max_batch = 256;  // frames per launch group (O3DR_BATCH_FRAMES); also bounded by a workspace budget
     int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs
     int scatter_ballot = 0;  // O3DR_SCATTER=ballot: the ballot-matching scatter instead of the lane-counting one
@@ -286,6 +292,7 @@ extern "C" void o3dr_default_params(o3dr_params* p)
     p->min_points_per_voxel = 1;    // pose.h:108
     p->dont_downsample = 0;
     p->sor_enable = 0;
+    p->blur_kernel = 1;             // pose.h:98
 }
 
 extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
@@ -358,6 +365,10 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     dev_release(c->st_out);
     dev_release(c->st_kp);
     dev_release(c->st_poses);
+    dev_release(c->bil_tab);
+    dev_release(c->st_blur);
+    dev_release(c->st_blur_in);
+    dev_release(c->st_hist);
     if (c->cloud_big) (void)hipFree(c->cloud_big);
     if (c->cloud_alt) (void)hipFree(c->cloud_alt);
     if (c->cc_big) (void)hipFree(c->cc_big);
@@ -605,11 +616,75 @@ static int zero_counters(o3dr_ctx* c, CloudCounters* dev)
     return O3DR_OK;
 }
 
+// weight tables of cv::bilateralFilter (OpenCV 3.1 smooth.cpp bilateralFilter_8u), built with the host's exp()
+static int bilateral_prepare(o3dr_ctx* c, int d, double sigma_color, double sigma_space)
+{
+    if (sigma_color <= 0) sigma_color = 1;
+    if (sigma_space <= 0) sigma_space = 1;
+    if (c->bil_valid && c->bil_d == d && c->bil_sc == sigma_color && c->bil_ss == sigma_space) return O3DR_OK;
+    const double gauss_color_coeff = -0.5 / (sigma_color * sigma_color);
+    const double gauss_space_coeff = -0.5 / (sigma_space * sigma_space);
+    int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) : d / 2;  // cvRound
+    if (radius < 1) radius = 1;
+    if (radius > kBilMaxRadius) return fail(O3DR_ERR_INVALID_ARG, "bilateral filter radius above 64 is not supported");
+    const int dd = 2 * radius + 1, tw = bilateral_tile_width(radius);
+    std::vector<float> tab(256 + 2 * (size_t)dd * dd);
+    for (int i = 0; i < 256; ++i) tab[i] = (float)std::exp(i * i * gauss_color_coeff);
+    int maxk = 0;
+    for (int i = -radius; i <= radius; ++i)
+        for (int j = -radius; j <= radius; ++j) {
+            const double r = std::sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            ++maxk;
+        }
+    int k = 0;
+    for (int i = -radius; i <= radius; ++i)
+        for (int j = -radius; j <= radius; ++j) {
+            const double r = std::sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            tab[256 + k] = (float)std::exp(r * r * gauss_space_coeff);
+            const int32_t ofs = i * tw + j;
+            memcpy(&tab[256 + maxk + k], &ofs, sizeof ofs);
+            ++k;
+        }
+    HIPCHK(hipStreamSynchronize(c->stream));  // earlier launches may still read the old table
+    c->bil_valid = false;
+    CHK(dev_ensure(c, c->bil_tab, (256 + 2 * (size_t)maxk) * sizeof(float)));
+    HIPCHK(hipMemcpy(c->bil_tab.p, tab.data(), (256 + 2 * (size_t)maxk) * sizeof(float), hipMemcpyHostToDevice));
+    c->bil_d = d;
+    c->bil_sc = sigma_color;
+    c->bil_ss = sigma_space;
+    c->bil_radius = radius;
+    c->bil_maxk = maxk;
+    c->bil_valid = true;
+    return O3DR_OK;
+}
+
+// blur_kernel > 1 (pose_functions.cpp:1040-1047): the frames' disparity images are filtered into a scratch
+// buffer the reprojection then reads.  Rewrites (disp, pitch, frame stride) in place.
+static int maybe_blur(o3dr_ctx* c, const uint8_t** disp_d, int64_t* pitch, int64_t* fstride, int rows, int cols, int frames)
+{
+    const int bk = c->params.blur_kernel;
+    if (bk <= 1) return O3DR_OK;
+    CHK(bilateral_prepare(c, bk, (double)(bk * 2), (double)(bk / 2)));
+    const int64_t out_pitch = cols, out_fstride = (int64_t)rows * cols;
+    CHK(dev_ensure(c, c->st_blur, (size_t)out_fstride * (size_t)frames + 16));
+    launch_bilateral(&c->prof, c->stream, *disp_d, *pitch, *fstride, rows, cols, frames, c->bil_radius, c->bil_maxk,
+                     (const float*)c->bil_tab.p, (uint8_t*)c->st_blur.p, out_pitch, out_fstride);
+    HIPCHK(hipGetLastError());
+    *disp_d = (const uint8_t*)c->st_blur.p;
+    *pitch = out_pitch;
+    *fstride = out_fstride;
+    return O3DR_OK;
+}
+
 // A1 (+A2) of one frame into `dst` (device).  n_valid ends up in ws.n_valid[0].
 static int run_reproject_single(o3dr_ctx* c, const uint8_t* disp_d, int64_t disp_pitch, const uint8_t* bgr_d,
                                 int64_t bgr_pitch, int rows, int cols, const GridShape& g, const float* T,
                                 const float* kp_d, int n_kp, o3dr_point* dst, const float* T_dev = nullptr)
 {
+    int64_t disp_fstride = 0;
+    CHK(maybe_blur(c, &disp_d, &disp_pitch, &disp_fstride, rows, cols, 1));
     ReprojectArgs a;
     fill_args(c, a, disp_d, disp_pitch, 0, bgr_d, bgr_pitch, 0, rows, cols, g, 0);
     if (T_dev) {  // pose already in HBM (one frame of a batched call)
@@ -1189,8 +1264,11 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
             bgr_d = bgr + (int64_t)f0 * bgr_frame_stride;
             poses_d = poses + 16 * (int64_t)f0;
         }
+        const uint8_t* dsp = (const uint8_t*)disp_d;
+        int64_t dsp_pitch = disp_pitch, dsp_fstride = disp_frame_stride;
+        CHK(maybe_blur(c, &dsp, &dsp_pitch, &dsp_fstride, rows, cols, nb));
         ReprojectArgs a;
-        fill_args(c, a, (const uint8_t*)disp_d, disp_pitch, disp_frame_stride, (const uint8_t*)bgr_d, bgr_pitch,
+        fill_args(c, a, dsp, dsp_pitch, dsp_fstride, (const uint8_t*)bgr_d, bgr_pitch,
                   bgr_frame_stride, rows, cols, g, g.n);
         a.xf_mode = 2;
         a.poses = (const float*)poses_d;
@@ -1403,6 +1481,63 @@ extern "C" int o3dr_cloud_big_partition(o3dr_ctx* c, const float gmin[3], const 
 // -------------------------------------------------------------------------------------------------
 // measurement hooks
 // -------------------------------------------------------------------------------------------------
+extern "C" int o3dr_bilateral_filter_u8(o3dr_ctx* c, const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
+                                        double sigma_color, double sigma_space, uint8_t* dst, int64_t dst_pitch, int32_t mem)
+{
+    CTX_ENTER(c);
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (rows < 0 || cols < 0) return fail(O3DR_ERR_INVALID_ARG, "negative image size");
+    if (rows == 0 || cols == 0) return O3DR_OK;
+    if (!src || !dst) return fail(O3DR_ERR_INVALID_ARG, "src / dst is NULL");
+    if (src_pitch < cols || dst_pitch < cols) return fail(O3DR_ERR_INVALID_ARG, "pitch smaller than a row");
+    CHK(bilateral_prepare(c, d, sigma_color, sigma_space));
+    const uint8_t* src_d = src;
+    uint8_t* dst_d = dst;
+    if (mem == O3DR_MEM_HOST) {
+        const void* p;
+        CHK(stage_in(c, c->st_blur_in, src, (size_t)src_pitch * rows, mem, &p));
+        src_d = (const uint8_t*)p;
+        CHK(dev_ensure(c, c->st_blur, (size_t)dst_pitch * rows));
+        dst_d = (uint8_t*)c->st_blur.p;
+    }
+    launch_bilateral(&c->prof, c->stream, src_d, src_pitch, 0, rows, cols, 1, c->bil_radius, c->bil_maxk,
+                     (const float*)c->bil_tab.p, dst_d, dst_pitch, 0);
+    HIPCHK(hipGetLastError());
+    if (mem == O3DR_MEM_HOST) {
+        // only the pixels are written back: padding bytes of the caller's rows stay untouched
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)dst_pitch, dst_d, (size_t)dst_pitch, (size_t)cols, (size_t)rows,
+                                hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_disparity_variance(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, int64_t disp_frame_stride,
+                                       int32_t rows, int32_t cols, int32_t n_frames, double* variance_out, int32_t mem)
+{
+    CTX_ENTER(c);
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (n_frames < 0 || rows <= 0 || cols <= 0) return fail(O3DR_ERR_INVALID_ARG, "bad image size / frame count");
+    if (n_frames == 0) return O3DR_OK;
+    if (!disp || !variance_out) return fail(O3DR_ERR_INVALID_ARG, "disp / variance_out is NULL");
+    if (disp_pitch < cols) return fail(O3DR_ERR_INVALID_ARG, "pitch smaller than a row");
+    if (n_frames > 1 && disp_frame_stride < (int64_t)rows * disp_pitch)
+        return fail(O3DR_ERR_INVALID_ARG, "frame stride smaller than a frame");
+    const GridShape g = grid_shape(c->params, rows, cols);
+    const void* disp_d;
+    CHK(stage_in(c, c->st_blur_in, disp, (size_t)disp_frame_stride * (n_frames - 1) + (size_t)disp_pitch * rows, mem, &disp_d));
+    const size_t hist_bytes = sizeof(unsigned long long) * 256 * (size_t)n_frames;
+    CHK(dev_ensure(c, c->st_hist, hist_bytes + sizeof(double) * (size_t)n_frames));
+    unsigned long long* hist = (unsigned long long*)c->st_hist.p;
+    double* var_d = (double*)((char*)c->st_hist.p + hist_bytes);
+    launch_disp_variance(&c->prof, c->stream, (const uint8_t*)disp_d, disp_pitch, disp_frame_stride, rows, cols, n_frames,
+                         c->params.bounding_box, g.cs, c->params.min_disparity, hist, var_d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(variance_out, var_d, sizeof(double) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return O3DR_OK;
+}
+
 extern "C" int o3dr_profile_enable(o3dr_ctx* c, int32_t kernel_id, int32_t enable)
 {
     CTX_ENTER(c);

@@ -195,6 +195,14 @@ void launch_frame_bbox(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int 
                        const uint32_t* n_kp, uint32_t* n_valid, float* mm, uint32_t* scan_partial);
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);
+// cv::bilateralFilter on u8 images; tab = color_weight[256] | space_weight[maxk] | tile offsets [maxk] (device)
+constexpr int kBilMaxRadius = 64;
+void launch_bilateral(Profiler* pf, hipStream_t s, const uint8_t* src, int64_t src_pitch, int64_t src_fstride, int rows,
+                      int cols, int frames, int radius, int maxk, const float* tab, uint8_t* dst, int64_t dst_pitch,
+                      int64_t dst_fstride);
+int bilateral_tile_width(int radius);
+void launch_disp_variance(Profiler* pf, hipStream_t s, const uint8_t* disp, int64_t pitch, int64_t fstride, int rows, int cols,
+                          int frames, int bb, int cs, double min_disp, unsigned long long* hist, double* var_out);
 void launch_bbox(Profiler* pf, hipStream_t s, const float* mm, int used, float* out6);
 int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, const uint32_t* n_dev, int64_t cap,
                int mm_used, double stddev_mul, o3dr_point* out, uint32_t* n_out_dev);

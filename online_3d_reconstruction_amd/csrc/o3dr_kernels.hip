@@ -526,6 +526,139 @@ __global__ __launch_bounds__(kPtThreads) void k_points_minmax(const o3dr_point* 
 }
 
 // =================================================================================================
+// Disparity pre-passes (A1 front end): cv::bilateralFilter (pose_functions.cpp:1040-1047) and the variance
+// gate (pose_functions.cpp:987-1028, pose.cpp:187-196).
+// =================================================================================================
+constexpr int kBilTY = 32, kBilTX = 64;  // outputs per workgroup: lane = column, 8 rows per lane
+
+__device__ __forceinline__ int reflect101(int p, int len)  // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// OpenCV 3.1 bilateralFilter_8u, one channel, as an x86-64 (SSE3) build evaluates it: neighbours in the order of
+// the space table, w = color_weight[|v - v0|] * space_weight[k] and v*w in fp32; groups of four reduced as
+// (a0+a1)+(a2+a3) and added to the running sums, the remaining < 4 one by one; result cvRound(sum / wsum).
+// tab: color_weight[256] | space_weight[maxk] | tile offsets dy * (kBilTX + 2 radius) + dx as int32 [maxk].
+__global__ __launch_bounds__(256) void k_bilateral_u8(const uint8_t* __restrict__ src, int64_t src_pitch, int64_t src_fstride,
+                                                      int rows, int cols, int radius, int maxk,
+                                                      const float* __restrict__ tab, uint8_t* __restrict__ dst,
+                                                      int64_t dst_pitch, int64_t dst_fstride, int tiles_x)
+{
+    extern __shared__ uint8_t bil_lds[];
+    const int TW = kBilTX + 2 * radius, TH = kBilTY + 2 * radius;
+    float* cw = reinterpret_cast<float*>(bil_lds);  // 256 floats
+    uint8_t* tile = bil_lds + 1024;
+    const int f = blockIdx.y;
+    const int y0 = ((int)blockIdx.x / tiles_x) * kBilTY, x0 = ((int)blockIdx.x % tiles_x) * kBilTX;
+    const uint8_t* sf = src + (int64_t)f * src_fstride;
+    cw[threadIdx.x] = tab[threadIdx.x];
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        tile[i] = sf[(int64_t)reflect101(y0 - radius + ty, rows) * src_pitch + reflect101(x0 - radius + tx, cols)];
+    }
+    __syncthreads();
+    const float* sw = tab + 256;
+    const int* ofs = reinterpret_cast<const int*>(tab + 256 + maxk);
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    constexpr int NO = kBilTY / 4;  // outputs per lane
+    int e0[NO], v0[NO];
+    float sum[NO], wsum[NO];
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+        e0[i] = (r0 + 4 * i + radius) * TW + (c + radius);
+        v0[i] = tile[e0[i]];
+        sum[i] = 0.f;
+        wsum[i] = 0.f;
+    }
+    int k = 0;
+    for (; k <= maxk - 4; k += 4) {
+        float swk[4];
+        int ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            swk[q] = sw[k + q];  // wave-uniform: scalar loads
+            ok[q] = ofs[k + q];
+        }
+#pragma unroll
+        for (int i = 0; i < NO; ++i) {
+            float w[4], vw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int val = tile[e0[i] + ok[q]];
+                w[q] = cw[abs(val - v0[i])] * swk[q];
+                vw[q] = w[q] * (float)val;
+            }
+            const float ws = (w[0] + w[1]) + (w[2] + w[3]);
+            const float vs = (vw[0] + vw[1]) + (vw[2] + vw[3]);
+            sum[i] += vs;
+            wsum[i] += ws;
+        }
+    }
+    for (; k < maxk; ++k) {
+        const float swk = sw[k];
+        const int ok = ofs[k];
+#pragma unroll
+        for (int i = 0; i < NO; ++i) {
+            const int val = tile[e0[i] + ok];
+            const float w = swk * cw[abs(val - v0[i])];
+            sum[i] += (float)val * w;
+            wsum[i] += w;
+        }
+    }
+    uint8_t* df = dst + (int64_t)f * dst_fstride;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+        const int y = y0 + r0 + 4 * i, x = x0 + c;
+        if (y < rows && x < cols) df[(int64_t)y * dst_pitch + x] = (uint8_t)__float2int_rn(sum[i] / wsum[i]);
+    }
+}
+
+// histogram of the ROI's valid disparities (d > min_disparity), one row of 256 counters per frame
+__global__ __launch_bounds__(256) void k_disp_hist(const uint8_t* __restrict__ disp, int64_t pitch, int64_t fstride, int rows,
+                                                   int cols, int bb, int cs, double min_disp,
+                                                   unsigned long long* __restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int W = cols - bb - cs;
+    const int y = bb + (int)blockIdx.x;
+    if (y < rows - bb && W > 0) {
+        const uint8_t* row = disp + (int64_t)f * fstride + (int64_t)y * pitch + cs;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            const uint32_t d = row[x];
+            if ((double)d > min_disp) atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[(int64_t)f * 256 + threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+// mean: the reference's sequential fp64 sum of integers is exact, so sum_d h[d] * d reproduces it bit for bit;
+// variance: sum_d h[d] * (d - mean)^2 in ascending d instead of pixel order (differs from the sequential sum only
+// by fp64 rounding, at most N * 2^-53 relative for N pixels)
+__global__ void k_disp_variance(const unsigned long long* __restrict__ hist, int frames, int rows, int cols, int bb, int cs,
+                                double* __restrict__ var_out)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    const unsigned long long* h = hist + (int64_t)f * 256;
+    unsigned long long s = 0;
+    for (int d = 0; d < 256; ++d) s += h[d] * (unsigned long long)d;
+    const int roi = (rows - 2 * bb) * (cols - bb - cs);
+    const double mean = (double)s / roi;
+    double temp = 0;
+    for (int d = 0; d < 256; ++d) temp += (double)h[d] * (((double)d - mean) * ((double)d - mean));
+    var_out[f] = temp / (roi - 1);
+}
+
+// =================================================================================================
 // Pixel-window voxel grouping (fused A6 path, rectified-stereo Q, small leaf).
 //   Two pixels can only fall into the same (voxel_size/5) voxel if they carry the same disparity byte and
 //   lie within W(d) = floor(1.01*leaf*sqrt(3) / (|Q0| * |1/w(d)|)) pixels of each other (the host checks that
@@ -2596,6 +2729,29 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             k_gather_heads<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(v.in, cap, ws.vals[0], ws.vals[1], ws.geom_runs,
                                                                                  ws.n_out, ws.out_off, v.out_base);
     }
+}
+
+void launch_bilateral(Profiler* pf, hipStream_t s, const uint8_t* src, int64_t src_pitch, int64_t src_fstride, int rows,
+                      int cols, int frames, int radius, int maxk, const float* tab, uint8_t* dst, int64_t dst_pitch,
+                      int64_t dst_fstride)
+{
+    if (rows <= 0 || cols <= 0 || frames <= 0) return;
+    const int tiles_x = cdiv64(cols, kBilTX), tiles_y = cdiv64(rows, kBilTY);
+    const size_t lds = 1024 + (size_t)(kBilTX + 2 * radius) * (kBilTY + 2 * radius);
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    k_bilateral_u8<<<dim3(tiles_x * tiles_y, frames), 256, lds, s>>>(src, src_pitch, src_fstride, rows, cols, radius, maxk, tab,
+                                                                    dst, dst_pitch, dst_fstride, tiles_x);
+}
+int bilateral_tile_width(int radius) { return kBilTX + 2 * radius; }
+
+void launch_disp_variance(Profiler* pf, hipStream_t s, const uint8_t* disp, int64_t pitch, int64_t fstride, int rows, int cols,
+                          int frames, int bb, int cs, double min_disp, unsigned long long* hist, double* var_out)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    (void)hipMemsetAsync(hist, 0, sizeof(unsigned long long) * 256 * (size_t)frames, s);
+    const int roi_rows = rows - 2 * bb;
+    if (roi_rows > 0) k_disp_hist<<<dim3(roi_rows, frames), 256, 0, s>>>(disp, pitch, fstride, rows, cols, bb, cs, min_disp, hist);
+    k_disp_variance<<<cdiv64(frames, 64), 64, 0, s>>>(hist, frames, rows, cols, bb, cs, var_out);
 }
 
 void launch_bbox(Profiler* pf, hipStream_t s, const float* mm, int used, float* out6)

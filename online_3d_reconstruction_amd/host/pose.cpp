@@ -53,6 +53,7 @@ void Pose::push_params(o3dr_ctx* c)
     p.min_points_per_voxel = min_points_per_voxel;
     p.dont_downsample = dont_downsample ? 1 : 0;
     p.sor_enable = sor ? 1 : 0;
+    p.blur_kernel = blur_kernel;  // > 1: bilateral filter on the disparity image first (pose_functions.cpp:1040-1047)
     chk(o3dr_set_params(c, &p), "o3dr_set_params");
     chk(o3dr_set_camera(c, Q.data()), "o3dr_set_camera");
 }
@@ -409,7 +410,7 @@ int Pose::parseCmdArgs(int argc, char** argv)
         else if (a == "--min_points_per_voxel") min_points_per_voxel = (unsigned)atoi(need(i));
         else if (a == "--jump_pixels") jump_pixels = atoi(need(i));
         else if (a == "--seq_len") seq_len = atoi(need(i));
-        else if (a == "--blur_kernel") { blur_kernel = atoi(need(i)); if (blur_kernel > 1) cout << "blur_kernel > 1 (bilateral filter) is not implemented in this build; ignored" << endl; blur_kernel = 1; }
+        else if (a == "--blur_kernel") blur_kernel = atoi(need(i));
         else if (a == "--log") log_stuff = atoi(need(i)) != 0;
         else if (a == "--dont_downsample") dont_downsample = true;
         else if (a == "--only_MAVLink") only_MAVLink = true;

@@ -561,3 +561,109 @@ int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_p
     free(j.out_n);
     return m;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * cv::bilateralFilter on CV_8UC1 — OpenCV 3.1.0 smooth.cpp, bilateralFilter_8u + BilateralFilter_8u_Invoker
+ * (called from pose_functions.cpp:1044)
+ * ------------------------------------------------------------------------------------------------ */
+static int reflect101(int p, int len) /* cv::borderInterpolate(p, len, BORDER_REFLECT_101) */
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0)
+            p = -p;
+        else
+            p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+void orc_bilateral_filter_u8(const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
+                             double sigma_color, double sigma_space, int32_t order, uint8_t* dst, int64_t dst_pitch)
+{
+    if (rows <= 0 || cols <= 0) return;
+    if (sigma_color <= 0) sigma_color = 1;
+    if (sigma_space <= 0) sigma_space = 1;
+    const double gauss_color_coeff = -0.5 / (sigma_color * sigma_color);
+    const double gauss_space_coeff = -0.5 / (sigma_space * sigma_space);
+    int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) /* cvRound */ : d / 2;
+    if (radius < 1) radius = 1;
+    d = radius * 2 + 1;
+
+    /* copyMakeBorder(src, temp, radius, radius, radius, radius, BORDER_DEFAULT) */
+    const int tw = cols + 2 * radius, th = rows + 2 * radius;
+    uint8_t* temp = (uint8_t*)malloc((size_t)tw * (size_t)th);
+    for (int y = 0; y < th; ++y) {
+        const uint8_t* srow = src + (int64_t)reflect101(y - radius, rows) * src_pitch;
+        for (int x = 0; x < tw; ++x) temp[(size_t)y * tw + x] = srow[reflect101(x - radius, cols)];
+    }
+    float color_weight[256];
+    float* space_weight = (float*)malloc(sizeof(float) * (size_t)d * d);
+    int* space_ofs = (int*)malloc(sizeof(int) * (size_t)d * d);
+    for (int i = 0; i < 256; ++i) color_weight[i] = (float)exp(i * i * gauss_color_coeff);
+    int maxk = 0;
+    for (int i = -radius; i <= radius; ++i)
+        for (int j = -radius; j <= radius; ++j) {
+            const double r = sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            space_weight[maxk] = (float)exp(r * r * gauss_space_coeff);
+            space_ofs[maxk++] = i * tw + j;
+        }
+    for (int i = 0; i < rows; ++i) {
+        const uint8_t* sptr = temp + (size_t)(i + radius) * tw + radius;
+        uint8_t* dptr = dst + (int64_t)i * dst_pitch;
+        for (int j = 0; j < cols; ++j) {
+            float sum = 0, wsum = 0;
+            const int val0 = sptr[j];
+            int k = 0;
+            if (order == ORC_BILATERAL_SSE3) {
+                for (; k <= maxk - 4; k += 4) {
+                    float w[4], vw[4];
+                    for (int q = 0; q < 4; ++q) {
+                        const int val = sptr[j + space_ofs[k + q]];
+                        w[q] = color_weight[abs(val - val0)] * space_weight[k + q]; /* mulps(_cw, _sw) */
+                        vw[q] = w[q] * (float)val;                                  /* mulps(_w, _valF) */
+                    }
+                    /* hadd(_w,_cw) -> hadd(.,.): [ (w0+w1)+(w2+w3), (vw0+vw1)+(vw2+vw3) ] */
+                    const float ws = (w[0] + w[1]) + (w[2] + w[3]);
+                    const float vs = (vw[0] + vw[1]) + (vw[2] + vw[3]);
+                    sum += vs;
+                    wsum += ws;
+                }
+            }
+            for (; k < maxk; ++k) {
+                const int val = sptr[j + space_ofs[k]];
+                const float w = space_weight[k] * color_weight[abs(val - val0)];
+                sum += val * w;
+                wsum += w;
+            }
+            dptr[j] = (uint8_t)lrintf(sum / wsum); /* cvRound: round half to even */
+        }
+    }
+    free(space_ofs);
+    free(space_weight);
+    free(temp);
+}
+
+/* Pose::getMean / Pose::getVariance, pose_functions.cpp:987-1028 (planeFitted == false) */
+double orc_disparity_variance(const uint8_t* disp, int64_t pitch, int32_t rows, int32_t cols, int32_t bounding_box,
+                              int32_t cols_start_aft_cutout, double min_disparity)
+{
+    const int bb = bounding_box, cs = cols_start_aft_cutout;
+    double sum = 0.0;
+    for (int y = bb; y < rows - bb; ++y)
+        for (int x = cs; x < cols - bb; ++x) {
+            const double v = (double)disp[(int64_t)y * pitch + x];
+            if (v > min_disparity) sum += v;
+        }
+    const double mean = sum / ((rows - 2 * bb) * (cols - bb - cs));
+    double temp = 0;
+    for (int y = bb; y < rows - bb; ++y)
+        for (int x = cs; x < cols - bb; ++x) {
+            const double v = (double)disp[(int64_t)y * pitch + x];
+            if (v > min_disparity) temp += (v - mean) * (v - mean);
+        }
+    return temp / ((rows - 2 * bb) * (cols - bb - cs) - 1);
+}

@@ -82,6 +82,23 @@ int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_p
                        uint32_t min_points_per_voxel, int32_t sor, int32_t threads, orc_point* cloud_big_out,
                        int64_t* n_big, orc_point* merged_out);
 
+/* A1 pre-pass — cv::bilateralFilter(disp, out, d, sigma_color, sigma_space) as called at
+ * pose_functions.cpp:1040-1047 with (blur_kernel, blur_kernel*2, blur_kernel/2): OpenCV 3.1.0
+ * modules/imgproc/src/smooth.cpp bilateralFilter_8u, single channel, BORDER_DEFAULT (reflect-101),
+ * non-IPP build (the IPP branch is compiled out in 3.1.0).  order: how the per-pixel float sums are grouped —
+ * ORC_BILATERAL_SSE3: groups of four neighbours reduced pairwise with haddps, then added (x86-64 builds, which
+ * the reference's CMakeCache.txt shows); ORC_BILATERAL_SCALAR: one neighbour after the other (builds without SSE3).
+ * The weight tables use the host's exp(); parity unpinned like the rest of this oracle. */
+#define ORC_BILATERAL_SSE3   0
+#define ORC_BILATERAL_SCALAR 1
+void orc_bilateral_filter_u8(const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
+                             double sigma_color, double sigma_space, int32_t order, uint8_t* dst, int64_t dst_pitch);
+
+/* frame gate — Pose::getVariance(disp, false), pose_functions.cpp:987-1028 (mean over the ROI of the
+ * disparities > min_disparity, divided by the full ROI size; sequential fp64 sums in row-major order). */
+double orc_disparity_variance(const uint8_t* disp, int64_t pitch, int32_t rows, int32_t cols, int32_t bounding_box,
+                              int32_t cols_start_aft_cutout, double min_disparity);
+
 /* voxel keys only (occupancy checks): writes the uint32 linear index PCL computes for each point,
  * returns 0, or ORC_STATUS_VOXEL_OVERFLOW when PCL would bail out (keys then undefined). */
 uint32_t orc_voxel_keys(const orc_point* in, int64_t n, const float leaf[3], uint32_t* keys,

@@ -53,6 +53,10 @@ def lib():
                                      vp, vp, vp]
         L.orc_voxel_keys.restype = u32
         L.orc_voxel_keys.argtypes = [vp, i64, vp, vp, vp, vp]
+        L.orc_bilateral_filter_u8.restype = None
+        L.orc_bilateral_filter_u8.argtypes = [vp, i64, i32, i32, i32, dbl, dbl, i32, vp, i64]
+        L.orc_disparity_variance.restype = dbl
+        L.orc_disparity_variance.argtypes = [vp, i64, i32, i32, i32, i32, dbl]
         _lib = L
     return _lib
 
@@ -182,3 +186,30 @@ def run_frames(disp, bgr, Q, poses, voxel_size, jump_pixels=1, min_points_per_vo
     if want_clouds:
         return big[: n_big.value].copy(), merged[:m].copy()
     return m
+
+
+BILATERAL_SSE3 = 0
+BILATERAL_SCALAR = 1
+
+
+def bilateral_filter(disp, d, sigma_color, sigma_space, order=BILATERAL_SSE3):
+    """cv::bilateralFilter on a u8 image (OpenCV 3.1 restatement) — pose_functions.cpp:1044"""
+    disp = np.ascontiguousarray(disp, np.uint8)
+    rows, cols = disp.shape
+    out = np.empty_like(disp)
+    lib().orc_bilateral_filter_u8(_p(disp), disp.strides[0], rows, cols, int(d), float(sigma_color), float(sigma_space),
+                                  int(order), _p(out), out.strides[0])
+    return out
+
+
+def blur_disparity(disp, blur_kernel, order=BILATERAL_SSE3):
+    """the call of pose_functions.cpp:1044: bilateralFilter(d=bk, sigmaColor=bk*2, sigmaSpace=bk/2 (integer division))"""
+    return bilateral_filter(disp, blur_kernel, blur_kernel * 2, blur_kernel // 2, order)
+
+
+def disparity_variance(disp, bounding_box=20, cutout_ratio=8, min_disparity=64.0):
+    """Pose::getVariance(disp, false) — pose_functions.cpp:1007-1028"""
+    disp = np.ascontiguousarray(disp, np.uint8)
+    rows, cols = disp.shape
+    return float(lib().orc_disparity_variance(_p(disp), disp.strides[0], rows, cols, bounding_box, int(cols / cutout_ratio),
+                                              float(min_disparity)))

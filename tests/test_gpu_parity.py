@@ -579,3 +579,82 @@ def test_A1_row_pitch_larger_than_width(ctx, orc, Q, frame_1249):
     ctx.set_params(_params(jump_pixels=1, voxel_size=0.05))
     got = ctx.createSingleImgPtCloud(disp, bgr)
     assert_points_equal(got, orc.create_single_img_pt_cloud(disp0, bgr0, Q, jump_pixels=1), "A1 padded rows")
+
+
+# ---- disparity pre-passes -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,d,sc,ss", [((720, 1280), 30, 60.0, 15.0), ((97, 211), 5, 10.0, 2.0), ((33, 70), 9, 18.0, 4.0),
+                                           ((3, 2), 30, 60.0, 15.0), ((1, 1), 7, 14.0, 3.0), ((64, 64), 0, 25.0, 3.0),
+                                           ((40, 300), 2, 4.0, 1.0), ((50, 50), 129, 30.0, 20.0)])
+def test_bilateral_filter_bit_exact(ctx, orc, shape, d, sc, ss):
+    """cv::bilateralFilter restatement: every output byte equals the oracle's (x86-64 summation order)"""
+    import torch
+    rng = np.random.default_rng(shape[0] * 1000 + d)
+    img = rng.integers(90, 135, shape).astype(np.uint8)
+    img[rng.random(shape) < 0.02] = 0
+    ref = orc.bilateral_filter(img, d, sc, ss)
+    got = ctx.bilateralFilter(img, d, sc, ss)
+    assert np.array_equal(got, ref)
+    got_dev = ctx.bilateralFilter(torch.from_numpy(img).cuda(), d, sc, ss).cpu().numpy()
+    assert np.array_equal(got_dev, ref)
+
+
+def test_bilateral_filter_rejects_huge_radius(ctx):
+    import online_3d_reconstruction_amd as o3dr
+    with pytest.raises(o3dr.O3drError):
+        ctx.bilateralFilter(np.zeros((8, 8), np.uint8), 131, 1.0, 1.0)
+
+
+def test_bilateral_real_frame_and_padded_rows(ctx, orc, frame_1249):
+    disp = frame_1249[0]
+    pad = np.zeros((720, 1280 + 19), np.uint8)
+    pad[:, :1280] = disp
+    view = pad[:, :1280]
+    assert np.array_equal(ctx.bilateralFilter(view, 9, 18, 4), orc.bilateral_filter(disp, 9, 18, 4))
+
+
+@pytest.mark.parametrize("jump,bk", [(15, 30), (1, 5)])
+def test_A6_with_blur_kernel(ctx, orc, Q, frame_1248, jump, bk):
+    """--blur_kernel > 1 (README.md:50 runs with 30): A6 on the filtered disparity image"""
+    disp, bgr = frame_1248
+    T = _pose(5)
+    ctx.set_camera(Q)
+    ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05, blur_kernel=bk))
+    got = ctx.createAndTransformPtCloud(disp, bgr, T)
+    ref = orc.create_and_transform_pt_cloud(orc.blur_disparity(disp, bk), bgr, Q, T, 0.05, jump_pixels=jump)[0]
+    assert_points_equal(got, ref, f"A6 with blur_kernel {bk}")
+    ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05))
+
+
+def test_A7_accumulate_with_blur_kernel(ctx, orc):
+    from online_3d_reconstruction_amd import synth
+    Qs = synth.camera_Q()
+    ctx.set_camera(Qs)
+    F = 3
+    disp, bgr = synth.make_frames(70, F, invalid_frac=0.02)
+    poses = synth.make_poses(70, F)
+    ctx.set_params(_params(jump_pixels=2, voxel_size=0.05, blur_kernel=7))
+    ctx.cloudBigReset()
+    ctx.accumulateFrames(disp, bgr, poses)
+    big = ctx.cloudBigRead()
+    blurred = np.stack([orc.blur_disparity(d, 7) for d in disp])
+    rbig, _, _ = _oracle_run(orc, Qs, blurred, bgr, poses, 0.05, 2, 1)
+    assert_points_equal(big, rbig, "cloud_big with blur_kernel 7")
+    ctx.set_params(_params(jump_pixels=2, voxel_size=0.05))
+
+
+def test_disparity_variance_gate(ctx, orc, frame_1248, frame_1249):
+    """Pose::getVariance: the histogram form agrees with the sequential sums to fp64 rounding"""
+    import torch
+    from online_3d_reconstruction_amd import synth
+    ctx.set_params(_params(jump_pixels=1, voxel_size=0.05))
+    stack = np.stack([frame_1248[0], frame_1249[0], synth.make_frame(3)[0], np.zeros((720, 1280), np.uint8)])
+    ref = np.array([orc.disparity_variance(d) for d in stack])
+    got = ctx.disparityVariance(stack)
+    got_dev = ctx.disparityVariance(torch.from_numpy(stack).cuda())
+    rel = np.abs(got - ref) / np.maximum(ref, 1e-300)
+    # sequential fp64 sums over the ROI's 748 000 pixels drift by up to N * 2^-53 ~ 8e-11 relative from the sum
+    # taken per disparity level; the tolerance is stated here, the decision `> 5` is checked below
+    assert rel.max() <= 1e-9, rel
+    assert np.array_equal(got, got_dev)
+    assert ref[3] == 0.0 and got[3] == 0.0
+    assert np.array_equal(got > 5.0, ref > 5.0)  # the decision of pose.cpp:189

@@ -279,3 +279,62 @@ def test_run_frames_threads_match_serial_composition(orc):
         ref_merged, _ = orc.downsample_pt_cloud(ref_big, vs, True, 1)
         assert np.array_equal(big.view(np.uint32), ref_big.view(np.uint32))
         assert np.array_equal(merged.view(np.uint32), ref_merged.view(np.uint32))
+
+
+# ---- disparity pre-passes: bilateral filter (pose_functions.cpp:1040-1047) and variance gate (:987-1028) -------
+def _bilateral_numpy(img, d, sc, ss):
+    """independent float64 statement of the bilateral filter (no fp32 ordering): the u8 result may differ from
+    the fp32 one only where the exact value sits next to a rounding boundary"""
+    radius = max(d // 2, 1)
+    gc, gs = -0.5 / (sc * sc), -0.5 / (ss * ss)
+    pad = np.pad(img.astype(np.float64), radius, mode="reflect")
+    num = np.zeros(img.shape)
+    den = np.zeros(img.shape)
+    H, W = img.shape
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            r2 = i * i + j * j
+            if np.sqrt(r2) > radius:
+                continue
+            nb = pad[radius + i:radius + i + H, radius + j:radius + j + W]
+            w = np.exp(r2 * gs) * np.exp((nb - img) ** 2 * gc)
+            num += nb * w
+            den += w
+    return num / den
+
+
+def test_bilateral_filter_properties(orc):
+    rng = np.random.default_rng(3)
+    flat = np.full((9, 13), 117, np.uint8)
+    assert np.all(orc.blur_disparity(flat, 30) == 117)                # constant image is a fixed point
+    img = rng.integers(95, 125, (37, 53)).astype(np.uint8)
+    for bk in (2, 5, 9):
+        out = orc.blur_disparity(img, bk)
+        exact = _bilateral_numpy(img, bk, bk * 2, max(bk // 2, 1) if bk // 2 > 0 else 1)
+        # fp32 sums against float64: the same integer except next to a .5 boundary
+        near_half = np.abs(exact - np.floor(exact) - 0.5) < 1e-3
+        assert np.all((out == np.rint(exact)) | near_half)
+        assert out.min() >= img.min() and out.max() <= img.max()     # a convex combination of neighbours
+    # an isolated step edge survives (range kernel): 60 levels apart with sigma_color 10
+    edge = np.full((21, 21), 70, np.uint8)
+    edge[:, 11:] = 130
+    out = orc.bilateral_filter(edge, 5, 10.0, 2.0)
+    assert np.all(out[:, :11] == 70) and np.all(out[:, 11:] == 130)
+    # both summation orders agree to a level
+    a, b = orc.blur_disparity(img, 9), orc.blur_disparity(img, 9, orc.BILATERAL_SCALAR)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    # images smaller than the radius (reflect-101 applied repeatedly), 1-pixel image
+    tiny = rng.integers(0, 256, (3, 2)).astype(np.uint8)
+    assert orc.blur_disparity(tiny, 30).shape == (3, 2)
+    assert orc.blur_disparity(np.array([[200]], np.uint8), 30)[0, 0] == 200
+
+
+def test_disparity_variance_matches_numpy(orc, frame_1248):
+    disp = frame_1248[0]
+    roi = disp[20:700, 160:1260].astype(np.float64)
+    valid = roi > 64
+    mean = roi[valid].sum() / roi.size                      # the reference divides by the full ROI size
+    var = ((roi[valid] - mean) ** 2).sum() / (roi.size - 1)
+    got = orc.disparity_variance(disp)
+    assert abs(got - var) <= 1e-9 * var
+    assert got < 5.0 or got >= 5.0  # (the gate of pose.cpp:187-196 compares against 5)
