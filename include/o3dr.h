@@ -190,14 +190,22 @@ int o3dr_create_and_transform_pt_cloud(o3dr_ctx* ctx,
 /* ---- A7: fan-out + accumulate (pose.cpp:365-434) and the final merge (pose.cpp:527-532) --------
  * The context owns `cloud_big` in HBM.  o3dr_accumulate_frames runs A6 for `n_frames` frames
  * (frame f at base + f*frame_stride; pose f at poses + 16*f) and appends the per-frame results in
- * frame order, entirely on the device and asynchronously (no host round trip per frame).  No
- * keypoint pass here: callers that need one use the single-frame entry points.
+ * frame order, entirely on the device and asynchronously (no host round trip per frame).
+ * o3dr_accumulate_frames_kp also runs the keypoint pass (active iff jump_pixels != 1, pose_functions.cpp:1057-1091):
+ * frame f's keypoints are kp_xy[2*kp_offsets[f] .. 2*kp_offsets[f+1]) (x,y float pairs, memory kind `mem`);
+ * kp_offsets is a HOST array of n_frames+1 non-decreasing entries; NULL = no keypoints.
  * `status_or` (host pointer, may be NULL) is written by o3dr_cloud_big_size/o3dr_finalize. */
 int o3dr_accumulate_frames(o3dr_ctx* ctx,
                            const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
                            const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch,
                            int32_t rows, int32_t cols,
                            const float* poses, int32_t n_frames, int32_t mem);
+int o3dr_accumulate_frames_kp(o3dr_ctx* ctx,
+                              const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
+                              const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch,
+                              int32_t rows, int32_t cols,
+                              const float* poses, int32_t n_frames,
+                              const float* kp_xy, const int64_t* kp_offsets, int32_t mem);
 /* reserve HBM for cloud_big (points); optional — it grows on demand */
 int o3dr_cloud_big_reserve(o3dr_ctx* ctx, int64_t n_points);
 int o3dr_cloud_big_reset(o3dr_ctx* ctx);

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("o3dr_downsample_pt_cloud", C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_create_and_transform_pt_cloud", C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _pi64, _pu32, _i32]),
     ("o3dr_accumulate_frames", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32]),
+    ("o3dr_accumulate_frames_kp", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32]),
     ("o3dr_cloud_big_reserve", C.c_int, [_vp, _i64]),
     ("o3dr_cloud_big_reset", C.c_int, [_vp]),
     ("o3dr_cloud_big_size", C.c_int, [_vp, _pi64, _pu32]),

@@ -268,8 +268,9 @@ class Context:
         return (out, st) if return_status else out
 
     # -- fan-out / accumulate / final merge ---------------------------------------------------------
-    def accumulateFrames(self, disp, bgr, poses):
-        """pose.cpp:365-434 for a stack of frames: disp [F,H,W] u8, bgr [F,H,W,3] u8, poses [F,4,4] f32."""
+    def accumulateFrames(self, disp, bgr, poses, keypoints=None):
+        """pose.cpp:365-434 for a stack of frames: disp [F,H,W] u8, bgr [F,H,W,3] u8, poses [F,4,4] f32;
+        keypoints: optional list of F arrays [n_f,2] of (x,y) floats (KeyPoint::pt), used iff jump_pixels != 1."""
         F, rows, cols = disp.shape
         if _is_torch(disp):
             assert disp.is_contiguous() and bgr.is_contiguous() and poses.is_contiguous()
@@ -284,6 +285,23 @@ class Context:
         pb, mem2, _k2 = _ptr(bgr)
         pp, mem3, _k3 = _ptr(poses)
         assert mem == mem2 == mem3
+        if keypoints is not None:
+            assert len(keypoints) == F
+            kps = [np.ascontiguousarray(k, np.float32).reshape(-1, 2) for k in keypoints]
+            offs = np.zeros(F + 1, np.int64)
+            offs[1:] = np.cumsum([len(k) for k in kps])
+            kp = np.concatenate(kps) if offs[-1] else np.zeros((0, 2), np.float32)
+            if mem == L.MEM_DEVICE:
+                import torch
+                kp_t = torch.from_numpy(kp).to(disp.device)
+                kp_ptr = kp_t.data_ptr()
+            else:
+                kp_ptr = kp.ctypes.data
+            L.check(self._lib.o3dr_accumulate_frames_kp(self._h, pd, dfs, dp, pb, bfs, bp, rows, cols, pp, F, kp_ptr,
+                                                        offs.ctypes.data, mem))
+            if mem == L.MEM_DEVICE:
+                L.check(self._lib.o3dr_ctx_synchronize(self._h))  # kp_t must outlive the launches
+            return
         L.check(self._lib.o3dr_accumulate_frames(self._h, pd, dfs, dp, pb, bfs, bp, rows, cols, pp, F, mem))
 
     def cloudBigReserve(self, n_points):

@@ -99,7 +99,7 @@ struct o3dr_ctx {
     SortStats* stats_dev = nullptr;    // device statistics (bench.py byte accounting)
     SortStats* stats_host = nullptr;   // pinned
 
-    DevBuf st_disp, st_bgr, st_in, st_out, st_kp, st_poses;
+    DevBuf st_disp, st_bgr, st_in, st_out, st_kp, st_kpoff, st_poses;
     // host-input streaming of o3dr_accumulate_frames: two staging sets, uploads on their own stream
     DevBuf st2_disp[2], st2_bgr[2], st2_poses[2];
     hipStream_t copy_stream = nullptr;
@@ -364,6 +364,7 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     dev_release(c->st_in);
     dev_release(c->st_out);
     dev_release(c->st_kp);
+    dev_release(c->st_kpoff);
     dev_release(c->st_poses);
     dev_release(c->bil_tab);
     dev_release(c->st_blur);
@@ -1164,9 +1165,9 @@ extern "C" int o3dr_cloud_big_transform(o3dr_ctx* c, const float T[16])
     return O3DR_OK;
 }
 
-extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
-                                      const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch, int32_t rows,
-                                      int32_t cols, const float* poses, int32_t n_frames, int32_t mem)
+static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
+                           const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch, int32_t rows, int32_t cols,
+                           const float* poses, int32_t n_frames, const float* kp_xy, const int64_t* kp_offsets, int32_t mem)
 {
     CTX_ENTER(c);
     if (!c->has_Q) return fail(O3DR_ERR_NOT_CONFIGURED, "o3dr_set_camera has not been called");
@@ -1177,28 +1178,57 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
     if (disp_frame_stride < (int64_t)rows * disp_pitch || bgr_frame_stride < (int64_t)rows * bgr_pitch)
         return fail(O3DR_ERR_INVALID_ARG, "frame stride smaller than a frame");
     const GridShape g = grid_shape(c->params, rows, cols);
-    if (g.n == 0) return O3DR_OK;  // jump_pixels == 0 without keypoints: nothing to add
+    // keypoint pass (pose_functions.cpp:1057-1091): active iff jump_pixels != 1, emitted before the grid points
+    int64_t kp_total = 0, kp_max = 0;
+    if (kp_offsets && c->params.jump_pixels != 1) {
+        for (int f = 0; f < n_frames; ++f) {
+            const int64_t k = kp_offsets[f + 1] - kp_offsets[f];
+            if (k < 0) return fail(O3DR_ERR_INVALID_ARG, "kp_offsets must not decrease");
+            if (k > kp_max) kp_max = k;
+        }
+        kp_total = kp_offsets[n_frames] - kp_offsets[0];
+        if (kp_total > 0 && !kp_xy) return fail(O3DR_ERR_INVALID_ARG, "kp_xy is NULL");
+        if (kp_total >= (int64_t)INT32_MAX) return fail(O3DR_ERR_INVALID_ARG, "too many keypoints");
+    }
+    const bool use_kp = kp_total > 0;
+    const int64_t cap = g.n + kp_max;  // points a frame can produce: capacity of every per-frame buffer below
+    if (cap == 0) return O3DR_OK;      // jump_pixels == 0 without keypoints: nothing to add
+    const float* kp_d = nullptr;
+    const int32_t* kpoff_d = nullptr;
+    std::vector<int32_t> kp_rel;
+    if (use_kp) {
+        const void* p;
+        CHK(stage_in(c, c->st_kp, kp_xy + 2 * kp_offsets[0], (size_t)kp_total * 2 * sizeof(float), mem, &p));
+        kp_d = (const float*)p;
+        kp_rel.resize((size_t)n_frames + 1);
+        for (int f = 0; f <= n_frames; ++f) kp_rel[f] = (int32_t)(kp_offsets[f] - kp_offsets[0]);
+        HIPCHK(hipStreamSynchronize(c->stream));  // an earlier call's launches may still read the offsets
+        CHK(dev_ensure(c, c->st_kpoff, kp_rel.size() * sizeof(int32_t)));
+        HIPCHK(hipMemcpy(c->st_kpoff.p, kp_rel.data(), kp_rel.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        kpoff_d = (const int32_t*)c->st_kpoff.p;
+    }
     float leaf[3], zo;
     uint32_t mp;
     downsample_leaf(c->params, 0, leaf, &mp, &zo);
     if (sor_on(c) && !c->params.dont_downsample) {
         // statistical outlier removal enabled: frames go through the single-cloud path one by one
-        CHK(ws_ensure(c, 1, g.n, true));
-        CHK(sor_ensure(c, g.n));
+        CHK(ws_ensure(c, 1, cap, true));
+        CHK(sor_ensure(c, cap));
         const void *disp_d, *bgr_d, *poses_d;
         for (int f = 0; f < n_frames; ++f) {
-            CHK(cloud_make_room(c, g.n));
+            CHK(cloud_make_room(c, cap));
             CHK(stage_in(c, c->st_disp, disp + (int64_t)f * disp_frame_stride, (size_t)disp_frame_stride, mem, &disp_d));
             CHK(stage_in(c, c->st_bgr, bgr + (int64_t)f * bgr_frame_stride, (size_t)bgr_frame_stride, mem, &bgr_d));
             CHK(stage_in(c, c->st_poses, poses + 16 * (int64_t)f, 16 * sizeof(float), mem, &poses_d));
             CHK(run_reproject_single(c, (const uint8_t*)disp_d, disp_pitch, (const uint8_t*)bgr_d, bgr_pitch, rows, cols, g,
-                                     nullptr, nullptr, 0, c->ws.pts, (const float*)poses_d));
+                                     nullptr, use_kp ? kp_d + 2 * (int64_t)kp_rel[f] : nullptr,
+                                     use_kp ? kp_rel[f + 1] - kp_rel[f] : 0, c->ws.pts, (const float*)poses_d));
             VoxelArgs v;
             v.in = c->ws.sor_pts;
             v.in_fstride = 0;
             v.n_dev = c->ws.sor_n;
             v.frames = 1;
-            v.cap = g.n;
+            v.cap = cap;
             v.leaf[0] = leaf[0];
             v.leaf[1] = leaf[1];
             v.leaf[2] = leaf[2];
@@ -1209,24 +1239,24 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
             v.passthrough = 0;
             v.stats = c->stats_dev;
             v.use_runs = 0;
-            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, g.n,
+            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap,
                                    (int)((g.n + kEmitTile - 1) / kEmitTile) + 1, 1.0, c->ws.sor_pts, c->ws.sor_n);
             launch_voxel_grid(&c->prof, c->stream, c->ws, v);
             HIPCHK(hipGetLastError());
-            c->cloud_ub += g.n;
+            c->cloud_ub += cap;
             if (mem == O3DR_MEM_HOST) HIPCHK(hipStreamSynchronize(c->stream));
         }
         return O3DR_OK;
     }
     int B = n_frames < c->max_batch ? n_frames : c->max_batch;
     {   // ~56 bytes of workspace per candidate point; keep a batch under 12 GiB of HBM (of 288)
-        const int64_t per_frame = 56 * g.n + (1 << 20);
+        const int64_t per_frame = 56 * cap + (1 << 20);
         const int64_t fit = ((int64_t)12 << 30) / per_frame;
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }
-    CHK(ws_ensure(c, B, g.n, true));
+    CHK(ws_ensure(c, B, cap, true));
     WindowPlan wplan;
-    const bool use_window = window_plan(c, g, rows, cols, leaf[0], &wplan);
+    const bool use_window = !use_kp && window_plan(c, g, rows, cols, leaf[0], &wplan);
 
     const bool streaming = mem == O3DR_MEM_HOST;
     if (streaming) {
@@ -1243,7 +1273,7 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
     int slot = 0;
     for (int f0 = 0; f0 < n_frames; f0 += B, slot ^= 1) {
         const int nb = (n_frames - f0) < B ? (n_frames - f0) : B;
-        CHK(cloud_make_room(c, (int64_t)nb * g.n));
+        CHK(cloud_make_room(c, (int64_t)nb * cap));
         const void *disp_d, *bgr_d, *poses_d;
         if (streaming) {
             const size_t db = (size_t)nb * disp_frame_stride, cb = (size_t)nb * bgr_frame_stride, pb = (size_t)nb * 16 * sizeof(float);
@@ -1269,10 +1299,12 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         CHK(maybe_blur(c, &dsp, &dsp_pitch, &dsp_fstride, rows, cols, nb));
         ReprojectArgs a;
         fill_args(c, a, dsp, dsp_pitch, dsp_fstride, (const uint8_t*)bgr_d, bgr_pitch,
-                  bgr_frame_stride, rows, cols, g, g.n);
+                  bgr_frame_stride, rows, cols, g, cap);
         a.xf_mode = 2;
         a.poses = (const float*)poses_d;
         launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
+        if (use_kp)
+            launch_keypoint_pass(&c->prof, c->stream, a, kp_d, 0, c->ws.pts, c->ws.n_kp, c->ws.mm, kpoff_d + f0, nb);
         if (use_window) {
             // bounding boxes only; the window kernel inside launch_voxel_grid redoes the reprojection in LDS
             wplan.a = a;
@@ -1284,10 +1316,10 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         VoxelArgs v;
         v.window = use_window ? &wplan : nullptr;
         v.in = c->ws.pts;
-        v.in_fstride = g.n;
+        v.in_fstride = cap;
         v.n_dev = c->ws.n_valid;
         v.frames = nb;
-        v.cap = g.n;
+        v.cap = cap;
         v.leaf[0] = leaf[0];
         v.leaf[1] = leaf[1];
         v.leaf[2] = leaf[2];
@@ -1301,11 +1333,27 @@ extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t 
         v.use_runs = 0;
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
-        c->cloud_ub += (int64_t)nb * g.n;
+        c->cloud_ub += (int64_t)nb * cap;
         if (streaming) HIPCHK(hipEventRecord(c->ev_done[slot], c->stream));
     }
     if (streaming) HIPCHK(hipStreamSynchronize(c->stream));  // the caller may reuse its host buffers
     return O3DR_OK;
+}
+
+extern "C" int o3dr_accumulate_frames(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
+                                      const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch, int32_t rows,
+                                      int32_t cols, const float* poses, int32_t n_frames, int32_t mem)
+{
+    return accumulate_impl(c, disp, disp_frame_stride, disp_pitch, bgr, bgr_frame_stride, bgr_pitch, rows, cols, poses, n_frames,
+                           nullptr, nullptr, mem);
+}
+extern "C" int o3dr_accumulate_frames_kp(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_stride, int64_t disp_pitch,
+                                         const uint8_t* bgr, int64_t bgr_frame_stride, int64_t bgr_pitch, int32_t rows,
+                                         int32_t cols, const float* poses, int32_t n_frames, const float* kp_xy,
+                                         const int64_t* kp_offsets, int32_t mem)
+{
+    return accumulate_impl(c, disp, disp_frame_stride, disp_pitch, bgr, bgr_frame_stride, bgr_pitch, rows, cols, poses, n_frames,
+                           kp_xy, kp_offsets, mem);
 }
 
 static int finalize_impl(o3dr_ctx* c, const float* gmin, const float* gmax, o3dr_point* out, int64_t out_capacity,

@@ -152,8 +152,9 @@ struct CloudCounters {
 struct Profiler;  // o3dr_api.hip
 
 void launch_minmax_init(Profiler* pf, hipStream_t s, float* mm, int64_t mm_stride, int slot, uint32_t* n_kp, int frames);
+// keypoint pass of `frames` frames (one workgroup each); kp_off = nullptr: a single frame with n_kp keypoints
 void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,
-                          o3dr_point* out, uint32_t* n_kp_out, float* mm);
+                          o3dr_point* out, uint32_t* n_kp_out, float* mm, const int32_t* kp_off = nullptr, int frames = 1);
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
                       uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, float* mm,
                       uint32_t* scan_partial);

@@ -326,15 +326,24 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
 }
 
 // keypoint pass (pose_functions.cpp:1057-1091): one workgroup walks the keypoints in order
+// one workgroup per frame; kp_off (optional) holds the frames' ranges in kp_xy, else all n_kp belong to frame 0
 __global__ __launch_bounds__(256) void k_keypoint_pass(ReprojectArgs a, const float* __restrict__ kp_xy, int n_kp,
-                                                       o3dr_point* __restrict__ out, uint32_t* __restrict__ n_kp_out,
-                                                       float* __restrict__ mm)
+                                                       const int32_t* __restrict__ kp_off, o3dr_point* __restrict__ out,
+                                                       uint32_t* __restrict__ n_kp_out, float* __restrict__ mm)
 {
     __shared__ uint32_t scan_lds[256 / 64 + 1];
     __shared__ float mm_lds[6 * 4];
+    const int f = blockIdx.x;
+    if (kp_off) {
+        kp_xy += 2 * (int64_t)kp_off[f];
+        n_kp = kp_off[f + 1] - kp_off[f];
+    }
+    const uint8_t* disp = a.disp + (int64_t)f * a.disp_fstride;
+    const uint8_t* bgr = a.bgr + (int64_t)f * a.bgr_fstride;
+    out += (int64_t)f * a.out_fstride;
     float m[12];
     const bool xf = a.xf_mode != 0;
-    for (int i = 0; i < 12; ++i) m[i] = (a.xf_mode == 2) ? a.poses[i] : a.T[i];
+    for (int i = 0; i < 12; ++i) m[i] = (a.xf_mode == 2) ? a.poses[16 * (int64_t)f + i] : a.T[i];
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     bool any = false;
@@ -346,9 +355,9 @@ __global__ __launch_bounds__(256) void k_keypoint_pass(ReprojectArgs a, const fl
         if (i < n_kp) {
             const int x = (int)kp_xy[2 * i], y = (int)kp_xy[2 * i + 1];
             if (x >= a.cs && x < a.cols - a.bb && y >= a.bb && y < a.rows - a.bb) {
-                const uint32_t d = a.disp[(int64_t)y * a.disp_pitch + x];
+                const uint32_t d = disp[(int64_t)y * a.disp_pitch + x];
                 if ((double)d > a.min_disp) {
-                    const uint8_t* px = a.bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
+                    const uint8_t* px = bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
                     p = reproject_one(a.Q, x, y, (double)d, px[0], px[1], px[2], m, xf);
                     ok = true;
                 }
@@ -367,8 +376,8 @@ __global__ __launch_bounds__(256) void k_keypoint_pass(ReprojectArgs a, const fl
         }
         base += total;
     }
-    if (threadIdx.x == 0) n_kp_out[0] = base;
-    block_minmax_store<4>(lo, hi, any, mm_lds, mm + (int64_t)a.n_tiles * 6);  // slot after the grid tiles
+    if (threadIdx.x == 0) n_kp_out[f] = base;
+    block_minmax_store<4>(lo, hi, any, mm_lds, mm + ((int64_t)f * a.mm_stride + a.n_tiles) * 6);  // slot after the grid tiles
 }
 
 // A2 alone: pcl::transformPointCloud on an existing cloud (also the in-place re-transform of
@@ -2478,10 +2487,10 @@ void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t va
 }
 
 void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,
-                          o3dr_point* out, uint32_t* n_kp_out, float* mm)
+                          o3dr_point* out, uint32_t* n_kp_out, float* mm, const int32_t* kp_off, int frames)
 {
     ProfScope ps(pf, O3DR_K_OTHER, s);
-    k_keypoint_pass<<<1, 256, 0, s>>>(a, kp_xy, n_kp, out, n_kp_out, mm);
+    k_keypoint_pass<<<frames, 256, 0, s>>>(a, kp_xy, n_kp, kp_off, out, n_kp_out, mm);
 }
 
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,

@@ -367,8 +367,8 @@ def test_config5_shape_4k_semidense(ctx, orc):
 
 
 # ---- A3b: statistical outlier removal (pose_functions.cpp:1673-1686) ---------------------------------
-def _sor_oracle_pipeline(orc, Q, disp, bgr, T, vs, jump):
-    world = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=jump), T)
+def _sor_oracle_pipeline(orc, Q, disp, bgr, T, vs, jump, kp_xy=None):
+    world = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=jump, kp_xy=kp_xy), T)
     kept, _ = orc.statistical_outlier_removal(world)
     return orc.downsample_pt_cloud(kept, vs, False, 1)[0], kept
 
@@ -658,3 +658,91 @@ def test_disparity_variance_gate(ctx, orc, frame_1248, frame_1249):
     assert np.array_equal(got, got_dev)
     assert ref[3] == 0.0 and got[3] == 0.0
     assert np.array_equal(got > 5.0, ref > 5.0)  # the decision of pose.cpp:189
+
+
+def test_seven_threads_one_context_each_plus_concurrent_merge(orc, Q, frame_1248, frame_1249):
+    """the reference's calling pattern (pose.cpp:392-413,447): 7 threads run A6 on different frames at once,
+    each on its own context, while another thread runs a combined downsample; every result equals the oracle's"""
+    import threading
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    frames = [frame_1248, frame_1249] + [synth.make_frame(i, invalid_frac=0.02) for i in range(5)]
+    poses = synth.make_poses(20, 7)
+    params = o3dr.Params(jump_pixels=3, voxel_size=0.05)
+    merge_in = random_cloud(200000, 5)
+    results, errors = [None] * 8, []
+
+    def frame_worker(i):
+        try:
+            with o3dr.Context(0, Q=Q, params=params) as c:
+                for _ in range(3):  # several calls per thread so that the threads really overlap
+                    results[i] = c.createAndTransformPtCloud(frames[i][0], frames[i][1], poses[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    def merge_worker():
+        try:
+            with o3dr.Context(0, Q=Q, params=params) as c:
+                for _ in range(3):
+                    results[7] = c.downsamplePtCloud(merge_in, True)
+        except Exception as e:  # noqa: BLE001
+            errors.append((7, repr(e)))
+
+    threads = [threading.Thread(target=frame_worker, args=(i,)) for i in range(7)] + [threading.Thread(target=merge_worker)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(7):
+        ref = orc.create_and_transform_pt_cloud(frames[i][0], frames[i][1], Q, poses[i], 0.05, jump_pixels=3)[0]
+        assert_points_equal(results[i], ref, f"thread {i}")
+    assert_points_equal(results[7], orc.downsample_pt_cloud(merge_in, 0.05, True, 1)[0], "concurrent merge")
+
+
+@pytest.mark.parametrize("jump,device", [(15, False), (0, False), (4, True), (1, False)])
+def test_A7_accumulate_with_keypoints(ctx, orc, Q, frame_1248, frame_1249, jump, device):
+    """batched A6 with the keypoint pass (pose_functions.cpp:1057-1091): ragged keypoint lists, one frame without
+    keypoints, keypoints outside the ROI / on invalid pixels; jump_pixels 1 ignores them, 0 has only them"""
+    import torch
+    from online_3d_reconstruction_amd import synth
+    rng = np.random.default_rng(17 + jump)
+    frames = [frame_1248, frame_1249, synth.make_frame(9, invalid_frac=0.05), synth.make_frame(10)]
+    disp = np.stack([f[0] for f in frames])
+    bgr = np.stack([f[1] for f in frames])
+    poses = synth.make_poses(30, 4)
+    kps = [np.column_stack([rng.uniform(-20, 1300, n), rng.uniform(-20, 740, n)]).astype(np.float32) for n in (700, 0, 1500, 33)]
+    ctx.set_camera(Q)
+    ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05))
+    ctx.cloudBigReset()
+    if device:
+        ctx.accumulateFrames(torch.from_numpy(disp).cuda(), torch.from_numpy(bgr).cuda(), torch.from_numpy(poses).cuda(), kps)
+    else:
+        ctx.accumulateFrames(disp, bgr, poses, kps)
+    big = ctx.cloudBigRead()
+    ref = np.concatenate([orc.create_and_transform_pt_cloud(disp[i], bgr[i], Q, poses[i], 0.05, jump_pixels=jump, kp_xy=kps[i])[0]
+                          for i in range(4)])
+    assert_points_equal(big, ref, f"cloud_big with keypoints, jump {jump}")
+    if jump == 1:  # dense mode has no keypoint pass (pose_functions.cpp:1057 `jump_pixels != 1`)
+        ctx.cloudBigReset()
+        ctx.accumulateFrames(disp, bgr, poses)
+        assert_points_equal(ctx.cloudBigRead(), big, "keypoints ignored at jump_pixels 1")
+
+
+def test_A7_accumulate_with_sor_and_keypoints(ctx, orc):
+    """the reference's literal config-1 path: keypoint pass + grid pass -> SOR -> voxel grid, batched call"""
+    from online_3d_reconstruction_amd import synth
+    rng = np.random.default_rng(8)
+    Qs = synth.camera_Q()
+    ctx.set_camera(Qs)
+    F = 2
+    disp, bgr = synth.make_frames(44, F, invalid_frac=0.02)
+    poses = synth.make_poses(44, F)
+    kps = [np.column_stack([rng.uniform(100, 1270, n), rng.uniform(10, 710, n)]).astype(np.float32) for n in (900, 400)]
+    ctx.set_params(_params(jump_pixels=15, voxel_size=0.05, sor_enable=True))
+    ctx.cloudBigReset()
+    ctx.accumulateFrames(disp, bgr, poses, kps)
+    big = ctx.cloudBigRead()
+    ref = np.concatenate([_sor_oracle_pipeline(orc, Qs, disp[i], bgr[i], poses[i], 0.05, 15, kp_xy=kps[i])[0] for i in range(F)])
+    assert_points_equal(big, ref, "cloud_big with SOR and keypoints")
+    ctx.set_params(_params(jump_pixels=15, voxel_size=0.05))
