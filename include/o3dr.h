@@ -79,6 +79,10 @@ typedef struct o3dr_params {
     int32_t  blur_kernel;          /* pose.h:98 blur_kernel = 1; > 1: the disparity image goes through
                                       cv::bilateralFilter(d = blur_kernel, sigmaColor = 2*blur_kernel,
                                       sigmaSpace = blur_kernel/2 (integer division)) first, pose_functions.cpp:1040-1047 */
+    int32_t  disparity_f64;        /* --use_segment_labels (pose_functions.cpp:1037,1102): the disparity images handed to
+                                      the frame calls are CV_64F (doubles, pitch and frame stride still in bytes) and
+                                      are read with at<double>; 0 = CV_8UC1.  Not combinable with blur_kernel > 1
+                                      (cv::bilateralFilter rejects CV_64F) */
 } o3dr_params;
 
 typedef struct o3dr_ctx o3dr_ctx; /* opaque */

@@ -27,7 +27,7 @@ class O3drError(RuntimeError):
 class ParamsStruct(C.Structure):
     _fields_ = [("min_disparity", C.c_double), ("voxel_size", C.c_double), ("bounding_box", C.c_int32),
                 ("cutout_ratio", C.c_int32), ("jump_pixels", C.c_int32), ("min_points_per_voxel", C.c_uint32),
-                ("dont_downsample", C.c_int32), ("sor_enable", C.c_int32), ("blur_kernel", C.c_int32)]
+                ("dont_downsample", C.c_int32), ("sor_enable", C.c_int32), ("blur_kernel", C.c_int32), ("disparity_f64", C.c_int32)]
 
 
 def lib_path():

@@ -27,11 +27,13 @@ class Params:
     dont_downsample: bool = False
     sor_enable: bool = False
     blur_kernel: int = 1
+    disparity_f64: bool = False  # --use_segment_labels: disparity images are float64
 
     def to_struct(self):
         return L.ParamsStruct(float(self.min_disparity), float(self.voxel_size), int(self.bounding_box),
                               int(self.cutout_ratio), int(self.jump_pixels), int(self.min_points_per_voxel),
-                              int(bool(self.dont_downsample)), int(bool(self.sor_enable)), int(self.blur_kernel))
+                              int(bool(self.dont_downsample)), int(bool(self.sor_enable)), int(self.blur_kernel),
+                              int(bool(self.disparity_f64)))
 
 
 def _is_torch(x):
@@ -112,10 +114,11 @@ class Context:
         if _is_torch(disp):
             rows, cols = disp.shape
             assert tuple(bgr.shape) == (rows, cols, 3)
-            return rows, cols, disp.stride(0), bgr.stride(0)
+            return rows, cols, disp.stride(0) * disp.element_size(), bgr.stride(0)
         rows, cols = disp.shape
-        assert disp.dtype == np.uint8 and bgr.dtype == np.uint8 and bgr.shape == (rows, cols, 3)
-        assert disp.strides[1] == 1 and bgr.strides[2] == 1 and bgr.strides[1] == 3
+        # u8 disparities, or float64 with Params.disparity_f64 (--use_segment_labels)
+        assert disp.dtype in (np.uint8, np.float64) and bgr.dtype == np.uint8 and bgr.shape == (rows, cols, 3)
+        assert disp.strides[1] == disp.itemsize and bgr.strides[2] == 1 and bgr.strides[1] == 3
         return rows, cols, disp.strides[0], bgr.strides[0]
 
     def _alloc_out(self, n, like):
@@ -274,10 +277,11 @@ class Context:
         F, rows, cols = disp.shape
         if _is_torch(disp):
             assert disp.is_contiguous() and bgr.is_contiguous() and poses.is_contiguous()
-            dfs, dp, bfs, bp = disp.stride(0), disp.stride(1), bgr.stride(0), bgr.stride(1)
+            es = disp.element_size()  # 1, or 8 with Params.disparity_f64
+            dfs, dp, bfs, bp = disp.stride(0) * es, disp.stride(1) * es, bgr.stride(0), bgr.stride(1)
             assert poses.dtype.__str__() == "torch.float32" and poses.numel() == F * 16
         else:
-            disp = np.ascontiguousarray(disp, np.uint8)
+            disp = np.ascontiguousarray(disp, np.float64 if np.asarray(disp).dtype == np.float64 else np.uint8)
             bgr = np.ascontiguousarray(bgr, np.uint8)
             poses = np.ascontiguousarray(poses, np.float32).reshape(F, 16)
             dfs, dp, bfs, bp = disp.strides[0], disp.strides[1], bgr.strides[0], bgr.strides[1]

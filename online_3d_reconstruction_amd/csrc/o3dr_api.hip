@@ -293,6 +293,7 @@ extern "C" void o3dr_default_params(o3dr_params* p)
     p->dont_downsample = 0;
     p->sor_enable = 0;
     p->blur_kernel = 1;             // pose.h:98
+    p->disparity_f64 = 0;           // use_segment_labels off
 }
 
 extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
@@ -491,12 +492,15 @@ extern "C" int64_t o3dr_max_points(o3dr_ctx* c, int32_t rows, int32_t cols)
     return grid_shape(c->params, rows, cols).n;
 }
 
-static int check_images(const uint8_t* disp, int64_t disp_pitch, const uint8_t* bgr, int64_t bgr_pitch, int rows,
-                        int cols)
+static int check_images(const o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, const uint8_t* bgr, int64_t bgr_pitch,
+                        int rows, int cols, int64_t disp_frame_stride = 0)
 {
     if (!disp || !bgr) return fail(O3DR_ERR_INVALID_ARG, "image pointer is NULL");
     if (rows <= 0 || cols <= 0) return fail(O3DR_ERR_INVALID_ARG, "rows/cols must be positive");
-    if (disp_pitch < cols || bgr_pitch < 3 * (int64_t)cols) return fail(O3DR_ERR_INVALID_ARG, "pitch smaller than a row");
+    const int64_t esz = c->params.disparity_f64 ? 8 : 1;
+    if (disp_pitch < esz * cols || bgr_pitch < 3 * (int64_t)cols) return fail(O3DR_ERR_INVALID_ARG, "pitch smaller than a row");
+    if (esz == 8 && (((uintptr_t)disp | (uintptr_t)disp_pitch | (uintptr_t)disp_frame_stride) & 7))
+        return fail(O3DR_ERR_INVALID_ARG, "CV_64F disparities must be 8-byte aligned (pointer, pitch, frame stride)");
     return O3DR_OK;
 }
 
@@ -519,7 +523,8 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
     a.Ny = g.Ny;
     a.Nx = g.Nx;
     a.n_tiles = (int)((g.n + kEmitTile - 1) / kEmitTile);
-    a.vec4 = (a.jump == 1 && (g.Nx % 4) == 0 && (g.cs % 4) == 0 && (disp_pitch % 4) == 0 && (bgr_pitch % 4) == 0 &&
+    a.disp_f64 = c->params.disparity_f64 ? 1 : 0;
+    a.vec4 = (!a.disp_f64 && a.jump == 1 && (g.Nx % 4) == 0 && (g.cs % 4) == 0 && (disp_pitch % 4) == 0 && (bgr_pitch % 4) == 0 &&
               (disp_fstride % 4) == 0 && (bgr_fstride % 4) == 0 && ((uintptr_t)disp % 4) == 0 &&
               ((uintptr_t)bgr % 4) == 0)
                  ? 1
@@ -528,7 +533,7 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
     a.min_disp = c->params.min_disparity;
     a.out_fstride = out_fstride;
     a.mm_stride = c->ws.mm_stride;
-    a.lut = c->q_lut_on ? c->q_lut : nullptr;
+    a.lut = (c->q_lut_on && !a.disp_f64) ? c->q_lut : nullptr;
 }
 
 // Pixel-window voxel grouping (o3dr_kernels.hip): decide whether a fused A6 batch may use it and build the
@@ -667,6 +672,8 @@ static int maybe_blur(o3dr_ctx* c, const uint8_t** disp_d, int64_t* pitch, int64
 {
     const int bk = c->params.blur_kernel;
     if (bk <= 1) return O3DR_OK;
+    if (c->params.disparity_f64)
+        return fail(O3DR_ERR_INVALID_ARG, "blur_kernel > 1 needs CV_8UC1 disparities (cv::bilateralFilter rejects CV_64F)");
     CHK(bilateral_prepare(c, bk, (double)(bk * 2), (double)(bk / 2)));
     const int64_t out_pitch = cols, out_fstride = (int64_t)rows * cols;
     CHK(dev_ensure(c, c->st_blur, (size_t)out_fstride * (size_t)frames + 16));
@@ -723,7 +730,7 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
     if (!c->has_Q) return fail(O3DR_ERR_NOT_CONFIGURED, "o3dr_set_camera has not been called");
     if (!n_out || !out) return fail(O3DR_ERR_INVALID_ARG, "out / n_out is NULL");
     if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
-    CHK(check_images(disp, disp_pitch, bgr, bgr_pitch, rows, cols));
+    CHK(check_images(c, disp, disp_pitch, bgr, bgr_pitch, rows, cols));
     if (n_kp < 0 || (n_kp > 0 && !kp_xy)) return fail(O3DR_ERR_INVALID_ARG, "bad keypoint list");
     if (c->params.jump_pixels == 1) n_kp = 0;  // :1057 keypoints are skipped when every pixel is taken
     const GridShape g = grid_shape(c->params, rows, cols);
@@ -1174,7 +1181,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
     if (n_frames < 0 || (n_frames > 0 && !poses)) return fail(O3DR_ERR_INVALID_ARG, "bad frame list");
     if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
     if (n_frames == 0) return O3DR_OK;
-    CHK(check_images(disp, disp_pitch, bgr, bgr_pitch, rows, cols));
+    CHK(check_images(c, disp, disp_pitch, bgr, bgr_pitch, rows, cols, disp_frame_stride));
     if (disp_frame_stride < (int64_t)rows * disp_pitch || bgr_frame_stride < (int64_t)rows * bgr_pitch)
         return fail(O3DR_ERR_INVALID_ARG, "frame stride smaller than a frame");
     const GridShape g = grid_shape(c->params, rows, cols);
@@ -1569,6 +1576,7 @@ extern "C" int o3dr_disparity_variance(o3dr_ctx* c, const uint8_t* disp, int64_t
     if (n_frames == 0) return O3DR_OK;
     if (!disp || !variance_out) return fail(O3DR_ERR_INVALID_ARG, "disp / variance_out is NULL");
     if (disp_pitch < cols) return fail(O3DR_ERR_INVALID_ARG, "pitch smaller than a row");
+    if (c->params.disparity_f64) return fail(O3DR_ERR_INVALID_ARG, "o3dr_disparity_variance takes CV_8UC1 images");
     if (n_frames > 1 && disp_frame_stride < (int64_t)rows * disp_pitch)
         return fail(O3DR_ERR_INVALID_ARG, "frame stride smaller than a frame");
     const GridShape g = grid_shape(c->params, rows, cols);

@@ -78,6 +78,7 @@ struct ReprojectArgs {
     int64_t out_fstride;  // points between consecutive frames' output regions
     int64_t mm_stride;    // bounding-box slots per frame
     const QLutEntry* lut; // 256 entries in HBM when Q has the rectified-stereo sparsity, else nullptr
+    int32_t disp_f64;     // disparity image holds doubles (CV_64F, --use_segment_labels) instead of bytes
 };
 
 // All per-batch device buffers.  Sizes are for `frames` frames of at most `cap` points each.

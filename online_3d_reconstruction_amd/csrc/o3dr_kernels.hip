@@ -164,19 +164,25 @@ __device__ __forceinline__ Pix reproject_one(const double* __restrict__ Q, int x
 }
 
 // disparity bytes of the (up to) 4 candidates of one lane; returns the validity mask
+// disparity image element: CV_8UC1, or CV_64F with --use_segment_labels (pose_functions.cpp:1037,1102)
+template <bool F64> struct DispT { using type = uint32_t; };
+template <> struct DispT<true> { using type = double; };
+
+template <bool F64>
 __device__ __forceinline__ uint32_t load_lane_disparities(const ReprojectArgs& a, const uint8_t* __restrict__ disp,
-                                                          int c0, int n_cand, int& x0, int& y0, uint32_t d[4])
+                                                          int c0, int n_cand, int& x0, int& y0,
+                                                          typename DispT<F64>::type d[4])
 {
     uint32_t valid = 0;
     if (c0 >= n_cand) return 0;
-    if (a.vec4) {  // 4 consecutive pixels of one row, 4-byte aligned
+    if (!F64 && a.vec4) {  // 4 consecutive pixels of one row, 4-byte aligned
         const int ry = c0 / a.Nx, rx = c0 - ry * a.Nx;
         y0 = a.bb + ry;
         x0 = a.cs + rx;
         const uint32_t w = *reinterpret_cast<const uint32_t*>(disp + (int64_t)y0 * a.disp_pitch + x0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            d[k] = (w >> (8 * k)) & 255u;
+            d[k] = (typename DispT<F64>::type)((w >> (8 * k)) & 255u);
             if ((double)d[k] > a.min_disp) valid |= 1u << k;
         }
     } else {
@@ -186,7 +192,12 @@ __device__ __forceinline__ uint32_t load_lane_disparities(const ReprojectArgs& a
             d[k] = 0;
             if (c < n_cand) {
                 const int ry = c / a.Nx, rx = c - ry * a.Nx;
-                d[k] = disp[(int64_t)(a.bb + ry * a.jump) * a.disp_pitch + (a.cs + rx * a.jump)];
+                const uint8_t* row = disp + (int64_t)(a.bb + ry * a.jump) * a.disp_pitch;
+                const int x = a.cs + rx * a.jump;
+                if (F64)
+                    d[k] = (typename DispT<F64>::type)reinterpret_cast<const double*>(row)[x];
+                else
+                    d[k] = (typename DispT<F64>::type)row[x];
                 if ((double)d[k] > a.min_disp) valid |= 1u << k;
             }
         }
@@ -195,6 +206,7 @@ __device__ __forceinline__ uint32_t load_lane_disparities(const ReprojectArgs& a
 }
 
 // pass 1: valid candidates per 1024-candidate tile (reads 1 byte per candidate)
+template <bool F64>
 __global__ __launch_bounds__(kEmitThreads) void k_reproject_count(ReprojectArgs a, uint32_t* __restrict__ tile_cnt)
 {
     __shared__ uint32_t lds[kEmitThreads / 64];
@@ -203,8 +215,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_count(ReprojectArgs 
     const int n_cand = a.Ny * a.Nx;
     const int c0 = tile * kEmitTile + threadIdx.x * kEmitPerLane;
     int x0 = 0, y0 = 0;
-    uint32_t d[4];
-    const uint32_t valid = load_lane_disparities(a, disp, c0, n_cand, x0, y0, d);
+    typename DispT<F64>::type d[4];
+    const uint32_t valid = load_lane_disparities<F64>(a, disp, c0, n_cand, x0, y0, d);
     const uint32_t s = wave_sum_u32(__popc(valid));
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_count(ReprojectArgs 
 }
 
 // pass 2: recompute, transform, compact in row-major order, write 16-byte points coalesced
+template <bool F64>
 __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a, o3dr_point* __restrict__ out,
                                                                  const uint32_t* __restrict__ tile_off,
                                                                  const uint32_t* __restrict__ n_kp,
@@ -253,15 +266,15 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
     }
 
     int x0 = 0, y0 = 0;
-    uint32_t d[4];
-    const uint32_t valid = load_lane_disparities(a, disp, c0, n_cand, x0, y0, d);
+    typename DispT<F64>::type d[4];
+    const uint32_t valid = load_lane_disparities<F64>(a, disp, c0, n_cand, x0, y0, d);
 
     Pix p[4];
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     if (valid) {
         uint32_t cb[4], cg[4], cr[4];
-        if (a.vec4) {  // 12 colour bytes of 4 pixels = 3 aligned dwords
+        if (!F64 && a.vec4) {  // 12 colour bytes of 4 pixels = 3 aligned dwords
             const uint32_t* q = reinterpret_cast<const uint32_t*>(bgr + (int64_t)y0 * a.bgr_pitch + 3 * (int64_t)x0);
             const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
             cb[0] = w0 & 255u;         cg[0] = (w0 >> 8) & 255u;  cr[0] = (w0 >> 16) & 255u;
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
         for (int k = 0; k < 4; ++k) {
             if (valid & (1u << k)) {
                 int x, y;
-                if (a.vec4) {
+                if (!F64 && a.vec4) {
                     x = x0 + k;
                     y = y0;
                 } else {
@@ -286,7 +299,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
                     cg[k] = px[1];
                     cr[k] = px[2];
                 }
-                if (a.lut) {
+                bool done = false;
+                if constexpr (!F64) {
+                  if (a.lut) {
+                    done = true;
                     // same arithmetic as reproject_one with the exact-zero terms of Q dropped (adding
                     // +-0 and multiplying by the tabulated 1./w change no bit of the result)
                     const double al = lut_alpha[d[k]];
@@ -301,9 +317,9 @@ __global__ __launch_bounds__(kEmitThreads) void k_reproject_emit(ReprojectArgs a
                         p[k].x = X; p[k].y = Y; p[k].z = Z;
                     }
                     p[k].rgba = (cr[k] << 16) | (cg[k] << 8) | cb[k];
-                } else {
-                    p[k] = reproject_one(a.Q, x, y, (double)d[k], cb[k], cg[k], cr[k], m, xf);
+                  }
                 }
+                if (!done) p[k] = reproject_one(a.Q, x, y, (double)d[k], cb[k], cg[k], cr[k], m, xf);
                 lo[0] = fminf(lo[0], p[k].x); hi[0] = fmaxf(hi[0], p[k].x);
                 lo[1] = fminf(lo[1], p[k].y); hi[1] = fmaxf(hi[1], p[k].y);
                 lo[2] = fminf(lo[2], p[k].z); hi[2] = fmaxf(hi[2], p[k].z);
@@ -355,10 +371,11 @@ __global__ __launch_bounds__(256) void k_keypoint_pass(ReprojectArgs a, const fl
         if (i < n_kp) {
             const int x = (int)kp_xy[2 * i], y = (int)kp_xy[2 * i + 1];
             if (x >= a.cs && x < a.cols - a.bb && y >= a.bb && y < a.rows - a.bb) {
-                const uint32_t d = disp[(int64_t)y * a.disp_pitch + x];
-                if ((double)d > a.min_disp) {
+                const uint8_t* row = disp + (int64_t)y * a.disp_pitch;
+                const double d = a.disp_f64 ? reinterpret_cast<const double*>(row)[x] : (double)row[x];
+                if (d > a.min_disp) {
                     const uint8_t* px = bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
-                    p = reproject_one(a.Q, x, y, (double)d, px[0], px[1], px[2], m, xf);
+                    p = reproject_one(a.Q, x, y, d, px[0], px[1], px[2], m, xf);
                     ok = true;
                 }
             }
@@ -697,7 +714,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_frame_bbox(ReprojectArgs a, ui
     for (int i = 0; i < 12; ++i) m[i] = T[i];
     int x0 = 0, y0 = 0;
     uint32_t d[4];
-    const uint32_t valid = load_lane_disparities(a, disp, c0, n_cand, x0, y0, d);
+    const uint32_t valid = load_lane_disparities<false>(a, disp, c0, n_cand, x0, y0, d);
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
@@ -2505,7 +2522,10 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     const dim3 grid(a.n_tiles, frames);
     {
         ProfScope ps(pf, O3DR_K_COUNT, s);
-        k_reproject_count<<<grid, kEmitThreads, 0, s>>>(a, tile_cnt);
+        if (a.disp_f64)
+            k_reproject_count<true><<<grid, kEmitThreads, 0, s>>>(a, tile_cnt);
+        else
+            k_reproject_count<false><<<grid, kEmitThreads, 0, s>>>(a, tile_cnt);
     }
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -2513,7 +2533,10 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     }
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
-        k_reproject_emit<<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr);
+        if (a.disp_f64)
+            k_reproject_emit<true><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr);
+        else
+            k_reproject_emit<false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr);
     }
 }
 
@@ -2582,7 +2605,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         }
         {
             ProfScope ps(pf, O3DR_K_REPROJECT, s);
-            k_reproject_emit<<<dim3(w->a.n_tiles, F), kEmitThreads, 0, s>>>(w->a, const_cast<o3dr_point*>(v.in), ws.tile_cnt,
+            k_reproject_emit<false><<<dim3(w->a.n_tiles, F), kEmitThreads, 0, s>>>(w->a, const_cast<o3dr_point*>(v.in), ws.tile_cnt,
                                                                              w->n_kp, ws.mm, ws.geom_gen);
         }
         {

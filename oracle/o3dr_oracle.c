@@ -52,12 +52,19 @@ static inline void reproject_pixel(const double Q[16], int x, int y, double d, c
     pt->rgba = ((uint32_t)bgr_px[2] << 16) | ((uint32_t)bgr_px[1] << 8) | (uint32_t)bgr_px[0];
 }
 
-int64_t orc_create_single_img_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
-                                       const uint8_t* bgr, int64_t bgr_pitch,
-                                       int32_t rows, int32_t cols, const double Q[16],
-                                       int32_t bounding_box, int32_t cols_start_aft_cutout,
-                                       double min_disparity, int32_t jump_pixels,
-                                       const float* kp_xy, int32_t n_kp, orc_point* out)
+/* dispImg.at<uchar>(y,x) or, with use_segment_labels, dispImg.at<double>(y,x) — pose_functions.cpp:1064-1069,1100-1105 */
+static inline double disp_at(const uint8_t* disp, int64_t pitch, int f64, int y, int x)
+{
+    const uint8_t* row = disp + (int64_t)y * pitch;
+    return f64 ? ((const double*)row)[x] : (double)row[x];
+}
+
+static int64_t create_single_impl(const uint8_t* disp, int64_t disp_pitch, int f64,
+                                  const uint8_t* bgr, int64_t bgr_pitch,
+                                  int32_t rows, int32_t cols, const double Q[16],
+                                  int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                  double min_disparity, int32_t jump_pixels,
+                                  const float* kp_xy, int32_t n_kp, orc_point* out)
 {
     int64_t n = 0;
     /* keypoint pass — pose_functions.cpp:1057-1091 */
@@ -66,7 +73,7 @@ int64_t orc_create_single_img_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
             const int x = (int)kp_xy[2 * i], y = (int)kp_xy[2 * i + 1]; /* :1061 float -> int */
             if (x >= cols_start_aft_cutout && x < cols - bounding_box && y >= bounding_box &&
                 y < rows - bounding_box) { /* :1062 */
-                const double d = (double)disp[(int64_t)y * disp_pitch + x];
+                const double d = disp_at(disp, disp_pitch, f64, y, x);
                 if (d > min_disparity) /* :1070 */
                     reproject_pixel(Q, x, y, d, bgr + (int64_t)y * bgr_pitch + 3 * (int64_t)x, &out[n++]);
             }
@@ -76,13 +83,34 @@ int64_t orc_create_single_img_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
     if (jump_pixels > 0) {
         for (int y = bounding_box; y < rows - bounding_box; y += jump_pixels) {
             for (int x = cols_start_aft_cutout; x < cols - bounding_box; x += jump_pixels) {
-                const double d = (double)disp[(int64_t)y * disp_pitch + x]; /* :1104 */
+                const double d = disp_at(disp, disp_pitch, f64, y, x); /* :1104 */
                 if (d > min_disparity)                                       /* :1107 */
                     reproject_pixel(Q, x, y, d, bgr + (int64_t)y * bgr_pitch + 3 * (int64_t)x, &out[n++]);
             }
         }
     }
     return n;
+}
+
+int64_t orc_create_single_img_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
+                                       const uint8_t* bgr, int64_t bgr_pitch,
+                                       int32_t rows, int32_t cols, const double Q[16],
+                                       int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                       double min_disparity, int32_t jump_pixels,
+                                       const float* kp_xy, int32_t n_kp, orc_point* out)
+{
+    return create_single_impl(disp, disp_pitch, 0, bgr, bgr_pitch, rows, cols, Q, bounding_box, cols_start_aft_cutout,
+                              min_disparity, jump_pixels, kp_xy, n_kp, out);
+}
+int64_t orc_create_single_img_pt_cloud_f64(const double* disp, int64_t disp_pitch_bytes,
+                                           const uint8_t* bgr, int64_t bgr_pitch,
+                                           int32_t rows, int32_t cols, const double Q[16],
+                                           int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                           double min_disparity, int32_t jump_pixels,
+                                           const float* kp_xy, int32_t n_kp, orc_point* out)
+{
+    return create_single_impl((const uint8_t*)disp, disp_pitch_bytes, 1, bgr, bgr_pitch, rows, cols, Q, bounding_box,
+                              cols_start_aft_cutout, min_disparity, jump_pixels, kp_xy, n_kp, out);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -39,6 +39,14 @@ int64_t orc_create_single_img_pt_cloud(const uint8_t* disp, int64_t disp_pitch,
                                        double min_disparity, int32_t jump_pixels,
                                        const float* kp_xy, int32_t n_kp, orc_point* out);
 
+/* A1 with --use_segment_labels: the disparity image is CV_64F (pose_functions.cpp:1037,1064-1069,1100-1105) */
+int64_t orc_create_single_img_pt_cloud_f64(const double* disp, int64_t disp_pitch_bytes,
+                                           const uint8_t* bgr, int64_t bgr_pitch,
+                                           int32_t rows, int32_t cols, const double Q[16],
+                                           int32_t bounding_box, int32_t cols_start_aft_cutout,
+                                           double min_disparity, int32_t jump_pixels,
+                                           const float* kp_xy, int32_t n_kp, orc_point* out);
+
 /* A2 — Pose::transformPtCloud, pose_functions.cpp:1358-1362 -> pcl::transformPointCloud (dense). */
 void orc_transform_pt_cloud(const orc_point* in, int64_t n, const float T[16], orc_point* out);
 

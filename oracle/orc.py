@@ -37,6 +37,8 @@ def lib():
         L.orc_create_single_img_pt_cloud.restype = i64
         L.orc_create_single_img_pt_cloud.argtypes = [vp, i64, vp, i64, i32, i32, vp, i32, i32, dbl, i32,
                                                      vp, i32, vp]
+        L.orc_create_single_img_pt_cloud_f64.restype = i64
+        L.orc_create_single_img_pt_cloud_f64.argtypes = L.orc_create_single_img_pt_cloud.argtypes
         L.orc_transform_pt_cloud.restype = None
         L.orc_transform_pt_cloud.argtypes = [vp, i64, vp, vp]
         L.orc_voxel_grid.restype = i64
@@ -83,7 +85,9 @@ def _kp(kp_xy):
 
 def create_single_img_pt_cloud(disp, bgr, Q, bounding_box=20, cutout_ratio=8, min_disparity=64.0,
                                jump_pixels=1, kp_xy=None):
-    disp = np.ascontiguousarray(disp, np.uint8)
+    """disp: u8 [H,W], or float64 [H,W] for the --use_segment_labels form (CV_64F disparities)"""
+    f64 = np.asarray(disp).dtype == np.float64
+    disp = np.ascontiguousarray(disp, np.float64 if f64 else np.uint8)
     bgr = np.ascontiguousarray(bgr, np.uint8)
     rows, cols = disp.shape
     assert bgr.shape == (rows, cols, 3)
@@ -91,9 +95,9 @@ def create_single_img_pt_cloud(disp, bgr, Q, bounding_box=20, cutout_ratio=8, mi
     kp = _kp(kp_xy)
     ny, nx, cs = grid_shape(rows, cols, bounding_box, cutout_ratio, jump_pixels)
     out = np.empty(ny * nx + len(kp), POINT)
-    n = lib().orc_create_single_img_pt_cloud(_p(disp), disp.strides[0], _p(bgr), bgr.strides[0], rows, cols,
-                                             _p(Q), bounding_box, cs, float(min_disparity), jump_pixels,
-                                             _p(kp), len(kp), _p(out))
+    fn = lib().orc_create_single_img_pt_cloud_f64 if f64 else lib().orc_create_single_img_pt_cloud
+    n = fn(_p(disp), disp.strides[0], _p(bgr), bgr.strides[0], rows, cols, _p(Q), bounding_box, cs, float(min_disparity),
+           jump_pixels, _p(kp), len(kp), _p(out))
     return out[:n].copy()
 
 

@@ -746,3 +746,35 @@ def test_A7_accumulate_with_sor_and_keypoints(ctx, orc):
     ref = np.concatenate([_sor_oracle_pipeline(orc, Qs, disp[i], bgr[i], poses[i], 0.05, 15, kp_xy=kps[i])[0] for i in range(F)])
     assert_points_equal(big, ref, "cloud_big with SOR and keypoints")
     ctx.set_params(_params(jump_pixels=15, voxel_size=0.05))
+
+
+@pytest.mark.parametrize("jump", [1, 7])
+def test_A1_A6_float64_disparities(ctx, orc, Q, frame_1248, jump):
+    """--use_segment_labels: the disparity image is CV_64F and read with at<double> (pose_functions.cpp:1037,1102)"""
+    import torch
+    disp8, bgr = frame_1248
+    rng = np.random.default_rng(jump)
+    disp = disp8.astype(np.float64) + rng.uniform(-0.5, 0.5, disp8.shape)  # plane-fitted: fractional values
+    disp[rng.random(disp.shape) < 0.03] = 64.0                              # exactly at the threshold: rejected (strict >)
+    kps = np.column_stack([rng.uniform(0, 1280, 300), rng.uniform(0, 720, 300)]).astype(np.float32)
+    T = _pose(2)
+    ctx.set_camera(Q)
+    ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05, disparity_f64=True))
+    try:
+        ref1 = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=jump, kp_xy=kps)
+        assert_points_equal(ctx.createSingleImgPtCloud(disp, bgr, kps), ref1, "A1 float64")
+        world = orc.transform_pt_cloud(ref1, T)
+        ref6 = orc.downsample_pt_cloud(world, 0.05, False, 1)[0]
+        assert_points_equal(ctx.createAndTransformPtCloud(disp, bgr, T, kps), ref6, "A6 float64")
+        got_dev = ctx.createAndTransformPtCloud(torch.from_numpy(disp).cuda(), torch.from_numpy(bgr).cuda(), T, kps)
+        from online_3d_reconstruction_amd.api import points_from_torch
+        assert_points_equal(points_from_torch(got_dev), ref6, "A6 float64, device pointers")
+        ctx.cloudBigReset()
+        ctx.accumulateFrames(np.stack([disp, disp]), np.stack([bgr, bgr]), np.stack([T, T]).astype(np.float32), [kps, kps])
+        assert_points_equal(ctx.cloudBigRead(), np.concatenate([ref6, ref6]), "A7 float64")
+        import online_3d_reconstruction_amd as o3dr
+        ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05, disparity_f64=True, blur_kernel=5))
+        with pytest.raises(o3dr.O3drError):  # cv::bilateralFilter rejects CV_64F
+            ctx.createSingleImgPtCloud(disp, bgr)
+    finally:
+        ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05))
