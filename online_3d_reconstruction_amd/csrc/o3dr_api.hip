@@ -89,6 +89,11 @@ struct o3dr_ctx {
     o3dr_point* cloud_alt = nullptr;  // second buffer: partition target / receive buffer of the exchange
     int64_t cloud_alt_cap = 0;
     int64_t cloud_ub = 0;          // host-side upper bound of cc_big->count
+    // running bounding box of cloud_big (min xyz, max xyz; device), kept by the frame calls so that the merge and
+    // o3dr_cloud_big_bbox need no pass over the cloud; invalid after appends / transforms / exchanges
+    float* cloud_box = nullptr;
+    bool cloud_box_valid = false;
+    int cloud_box_enable = 1;  // O3DR_NO_CLOUD_BOX=1: always take the bounding box with a pass over the cloud
     CloudCounters* cc_big = nullptr;   // device
     CloudCounters* cc_tmp = nullptr;   // device, for single-shot calls
     CloudCounters* cc_host = nullptr;  // pinned
@@ -186,6 +191,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_nr = off;    off += align256((size_t)F * 4);
         size_t o_geomg = off; off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_winc = off;  off += align256((size_t)F * 2 * sizeof(float));
+        size_t o_omm = off;   off += align256((E / 64 + 8 * (size_t)F + 64) * 6 * sizeof(float));
+        size_t o_ommp = off;  off += align256(64 * 6 * sizeof(float));
         CHK(dev_ensure(c, c->ws_block, off));
         char* base = (char*)c->ws_block.p;
         Workspace& w = c->ws;
@@ -201,6 +208,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.n_runs = (uint32_t*)(base + o_nr);
         w.geom_gen = (VoxelGeom*)(base + o_geomg);
         w.win_c = (float*)(base + o_winc);
+        w.out_mm = (float*)(base + o_omm);
+        w.out_mm_partial = (float*)(base + o_ommp);
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
@@ -296,6 +305,8 @@ extern "C" void o3dr_default_params(o3dr_params* p)
     p->disparity_f64 = 0;           // use_segment_labels off
 }
 
+static int cloud_box_clear(o3dr_ctx* c);
+
 extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
 {
     if (!out_ctx) return fail(O3DR_ERR_INVALID_ARG, "out_ctx is NULL");
@@ -315,7 +326,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
         return fail(O3DR_ERR_NO_DEVICE, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
-    if (hipMalloc((void**)&c->cc_big, sizeof(CloudCounters)) != hipSuccess ||
+    if (hipMalloc((void**)&c->cloud_box, 6 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->cc_big, sizeof(CloudCounters)) != hipSuccess ||
         hipMalloc((void**)&c->cc_tmp, sizeof(CloudCounters)) != hipSuccess ||
         hipHostMalloc((void**)&c->cc_host, sizeof(CloudCounters), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->n_host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
@@ -342,12 +354,14 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (hb_env && atoi(hb_env) > 0) c->host_batch = atoi(hb_env);
     const char* ru_env = getenv("O3DR_RUNS");
     if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;
+    if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
     const char* wi_env = getenv("O3DR_WINDOW");
     c->win_enable = (wi_env && atoi(wi_env) == 1) ? 1 : 0;
     const char* sc_env = getenv("O3DR_SCATTER");
     c->scatter_ballot = (sc_env && strcmp(sc_env, "ballot") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
     if (env && atoi(env) > 0) c->max_batch = atoi(env) > 512 ? 512 : atoi(env);
+    (void)cloud_box_clear(c);
     *out_ctx = c;
     return O3DR_OK;
 }
@@ -373,6 +387,7 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     dev_release(c->st_hist);
     if (c->cloud_big) (void)hipFree(c->cloud_big);
     if (c->cloud_alt) (void)hipFree(c->cloud_alt);
+    if (c->cloud_box) (void)hipFree(c->cloud_box);
     if (c->cc_big) (void)hipFree(c->cc_big);
     if (c->cc_tmp) (void)hipFree(c->cc_tmp);
     if (c->cc_host) (void)hipHostFree(c->cc_host);
@@ -871,13 +886,16 @@ static int put_bbox(o3dr_ctx* c, const float mn[3], const float mx[3])
 
 static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const float leaf[3], uint32_t min_points,
                         float z_offset, o3dr_point* out_d, int64_t* n_out, uint32_t* status,
-                        const float* gmin = nullptr, const float* gmax = nullptr, bool do_sor = false)
+                        const float* gmin = nullptr, const float* gmax = nullptr, bool do_sor = false,
+                        const float* box_dev = nullptr)
 {
     CHK(ws_ensure(c, 1, n_in, false));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
     int mm_used = 1;
     if (gmin && gmax)  // grid laid over a caller-supplied (global) box instead of this cloud's own
         CHK(put_bbox(c, gmin, gmax));
+    else if (box_dev)  // the cloud's own box is already known on the device
+        HIPCHK(hipMemcpyAsync(c->ws.mm, box_dev, 6 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     else
         mm_used = launch_points_minmax(&c->prof, c->stream, in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
     CHK(zero_counters(c, c->cc_tmp));
@@ -1091,10 +1109,20 @@ extern "C" int o3dr_cloud_big_reserve(o3dr_ctx* c, int64_t n_points)
     return cloud_reserve(c, n_points);
 }
 
+static int cloud_box_clear(o3dr_ctx* c)
+{
+    static const float empty[6] = {__builtin_inff(), __builtin_inff(), __builtin_inff(),
+                                   -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    HIPCHK(hipMemcpyAsync(c->cloud_box, empty, sizeof empty, hipMemcpyHostToDevice, c->stream));
+    c->cloud_box_valid = c->cloud_box_enable != 0;
+    return O3DR_OK;
+}
+
 extern "C" int o3dr_cloud_big_reset(o3dr_ctx* c)
 {
     CTX_ENTER(c);
     CHK(zero_counters(c, c->cc_big));
+    CHK(cloud_box_clear(c));
     c->cloud_ub = 0;
     return O3DR_OK;
 }
@@ -1154,6 +1182,7 @@ extern "C" int o3dr_cloud_big_append(o3dr_ctx* c, const o3dr_point* pts, int64_t
     v.passthrough = 1;
     v.mm_used = 0;
     v.stats = nullptr;
+    c->cloud_box_valid = false;  // appended points are not tracked
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     c->cloud_ub += n;
@@ -1169,6 +1198,7 @@ extern "C" int o3dr_cloud_big_transform(o3dr_ctx* c, const float T[16])
     CHK(read_counters(c, c->cc_big, &cc));
     launch_transform(&c->prof, c->stream, c->cloud_big, (int64_t)cc.count, T, c->cloud_big);
     HIPCHK(hipGetLastError());
+    c->cloud_box_valid = false;
     return O3DR_OK;
 }
 
@@ -1246,6 +1276,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
             v.passthrough = 0;
             v.stats = c->stats_dev;
             v.use_runs = 0;
+            v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
             v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap,
                                    (int)((g.n + kEmitTile - 1) / kEmitTile) + 1, 1.0, c->ws.sor_pts, c->ws.sor_n);
             launch_voxel_grid(&c->prof, c->stream, c->ws, v);
@@ -1322,6 +1353,8 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
                              c->ws.scan_partial);
         VoxelArgs v;
         v.window = use_window ? &wplan : nullptr;
+        if (use_window) c->cloud_box_valid = false;  // the window path's gather does not track it
+        v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
         v.in = c->ws.pts;
         v.in_fstride = cap;
         v.n_dev = c->ws.n_valid;
@@ -1394,7 +1427,8 @@ static int finalize_impl(o3dr_ctx* c, const float* gmin, const float* gmax, o3dr
     }
     int64_t m = 0;
     uint32_t st = 0;
-    CHK(voxel_single(c, c->cloud_big, n, leaf, mp, zo, out_d, &m, &st, gmin, gmax));
+    CHK(voxel_single(c, c->cloud_big, n, leaf, mp, zo, out_d, &m, &st, gmin, gmax, false,
+                     c->cloud_box_valid ? c->cloud_box : nullptr));
     if (mem == O3DR_MEM_HOST) {
         if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
         if (m > 0) {
@@ -1460,6 +1494,7 @@ extern "C" int o3dr_cloud_big_adopt(o3dr_ctx* c, int64_t n_points)
     HIPCHK(hipMemcpyAsync(&c->cc_big->count, &h->count, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     swap_clouds(c);
+    c->cloud_box_valid = false;
     c->cloud_ub = n_points;
     return O3DR_OK;
 }
@@ -1476,12 +1511,16 @@ extern "C" int o3dr_cloud_big_bbox(o3dr_ctx* c, float mn[3], float mx[3], int64_
     for (int a = 0; a < 3; ++a) mn[a] = __builtin_inff(), mx[a] = -__builtin_inff();
     if (n == 0) return O3DR_OK;
     if (n >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
-    CHK(ws_ensure(c, 1, n, false));
-    launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n, 1);
-    const int used = launch_points_minmax(&c->prof, c->stream, c->cloud_big, 0, c->ws.n_valid, 1, n, c->ws.mm_stride, c->ws.mm);
-    launch_bbox(&c->prof, c->stream, c->ws.mm, used, (float*)c->misc_dev);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->misc_host, c->misc_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (c->cloud_box_valid) {
+        HIPCHK(hipMemcpyAsync(c->misc_host, c->cloud_box, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        CHK(ws_ensure(c, 1, n, false));
+        launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n, 1);
+        const int used = launch_points_minmax(&c->prof, c->stream, c->cloud_big, 0, c->ws.n_valid, 1, n, c->ws.mm_stride, c->ws.mm);
+        launch_bbox(&c->prof, c->stream, c->ws.mm, used, (float*)c->misc_dev);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->misc_host, c->misc_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     const float* h = (const float*)c->misc_host;
     for (int a = 0; a < 3; ++a) mn[a] = h[a], mx[a] = h[3 + a];

@@ -121,6 +121,8 @@ struct Workspace {
     VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of runs, records starting in buffer 1
     VoxelGeom* geom_gen = nullptr;   // frames: geom with n = 0 for frames taken by the pixel-window path
     float* win_c = nullptr;          // frames*2: per-frame factors on the window table (k_window_plan)
+    float* out_mm = nullptr;         // frames*ceil(cap/256)*4*6: bounding boxes of what k_centroid's waves appended
+    float* out_mm_partial = nullptr; // 64*6
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
     int64_t mm_stride = 0;         // slots per frame
     uint32_t* n_valid = nullptr;   // frames     points per frame after A1
@@ -180,6 +182,7 @@ struct VoxelArgs {
     int mm_used;      // bounding-box slots to fold per frame
     SortStats* stats; // optional device statistics
     int use_runs;     // sort runs of consecutive equal indices instead of points (whole-cloud calls)
+    float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
     const struct WindowPlan* window = nullptr;  // non-null: fused A6 batch whose frames may take the pixel-window path
 };
 // Pixel-window voxel grouping of the fused per-frame path (o3dr_kernels.hip, "Pixel-window voxel grouping").

@@ -1851,57 +1851,101 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
                                                          const VoxelGeom* __restrict__ geom,
                                                          const uint32_t* __restrict__ n_out,
                                                          const uint64_t* __restrict__ out_off, float z_offset,
-                                                         int passthrough, o3dr_point* __restrict__ out_base)
+                                                         int passthrough, o3dr_point* __restrict__ out_base,
+                                                         float* __restrict__ out_mm)
 {
     const int f = blockIdx.y;
     const int64_t o = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
-    if (o >= n_out[f]) return;
-    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
-    uint4* dst = reinterpret_cast<uint4*>(out_base + out_off[f]);
-    if (passthrough) {
-        dst[o] = src[o];
-        return;
-    }
     const VoxelGeom g = geom[f];
-    if (g.n == 0) return;  // frame taken by the pixel-window path (k_gather_heads writes it)
-    if (g.overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
-        uint4 v = src[o];
-        v.z = __float_as_uint((__uint_as_float(v.z) + z_offset) - z_offset);
-        dst[o] = v;
-        return;
+    const bool active = o < n_out[f] && (passthrough || g.n != 0);  // g.n == 0: frame taken by the pixel-window path
+    if (!out_mm && !active) return;
+    if (__ballot(active) == 0ull) return;  // whole wave idle (k_cloud_bbox_fold skips its slot by the same test)
+    uint4 res = make_uint4(0, 0, 0, 0);
+    if (active) {
+        const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+        if (passthrough) {
+            res = src[o];
+        } else if (g.overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
+            res = src[o];
+            res.z = __float_as_uint((__uint_as_float(res.z) + z_offset) - z_offset);
+        } else {
+            const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
+            const uint32_t* pid = sorted_buf(g, vals0, vals1) + (int64_t)f * cap;
+            const uint32_t v = keep_idx ? keep_idx[(int64_t)f * cap + o] : (uint32_t)o;
+            const uint32_t b = ss[v], e = ss[v + 1];
+            float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
+            // the sums are strictly sequential (input order); the loads are not: 8 gathers in flight
+            for (uint32_t li = b; li < e; li += 8) {
+                uint32_t id[8];
+                uint4 p[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) id[k] = (li + k < e) ? pid[li + k] : 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (id[k] != 0xffffffffu) p[k] = src[id[k]];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (id[k] != 0xffffffffu) {
+                        sx += __uint_as_float(p[k].x);
+                        sy += __uint_as_float(p[k].y);
+                        sz += __uint_as_float(p[k].z) + z_offset;
+                        sr += (float)((p[k].w >> 16) & 255u);
+                        sg += (float)((p[k].w >> 8) & 255u);
+                        sb += (float)(p[k].w & 255u);
+                        sa += (float)(p[k].w >> 24);
+                    }
+                }
+            }
+            const float nf = (float)(e - b);
+            const float cx = sx / nf, cy = sy / nf, cz = sz / nf - z_offset;
+            const uint32_t rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) | ((uint32_t)(sg / nf) << 8) |
+                                  (uint32_t)(sb / nf);
+            res = make_uint4(__float_as_uint(cx), __float_as_uint(cy), __float_as_uint(cz), rgba);
+        }
+        reinterpret_cast<uint4*>(out_base + out_off[f])[o] = res;
     }
-    const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
-    const uint32_t* pid = sorted_buf(g, vals0, vals1) + (int64_t)f * cap;
-    const uint32_t v = keep_idx ? keep_idx[(int64_t)f * cap + o] : (uint32_t)o;
-    const uint32_t b = ss[v], e = ss[v + 1];
-    float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
-    // the sums are strictly sequential (input order); the loads are not: 8 gathers in flight
-    for (uint32_t li = b; li < e; li += 8) {
-        uint32_t id[8];
-        uint4 p[8];
+    if (out_mm) {  // bounding box of what this wave appended (folded into cloud_big's box by k_cloud_bbox_fold)
+        float* slot = out_mm + (((int64_t)f * gridDim.x + blockIdx.x) * (kPtThreads / 64) + (threadIdx.x >> 6)) * 6;
+        const float c3[3] = {__uint_as_float(res.x), __uint_as_float(res.y), __uint_as_float(res.z)};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) id[k] = (li + k < e) ? pid[li + k] : 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (id[k] != 0xffffffffu) p[k] = src[id[k]];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (id[k] != 0xffffffffu) {
-                sx += __uint_as_float(p[k].x);
-                sy += __uint_as_float(p[k].y);
-                sz += __uint_as_float(p[k].z) + z_offset;
-                sr += (float)((p[k].w >> 16) & 255u);
-                sg += (float)((p[k].w >> 8) & 255u);
-                sb += (float)(p[k].w & 255u);
-                sa += (float)(p[k].w >> 24);
+        for (int a = 0; a < 3; ++a) {
+            const float l = wave_min_f32(active ? c3[a] : __builtin_inff());
+            const float h = wave_max_f32(active ? c3[a] : -__builtin_inff());
+            if ((threadIdx.x & 63) == 0) {
+                slot[a] = l;
+                slot[3 + a] = h;
             }
         }
     }
-    const float nf = (float)(e - b);
-    const float cx = sx / nf, cy = sy / nf, cz = sz / nf - z_offset;
-    const uint32_t rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) | ((uint32_t)(sg / nf) << 8) |
-                          (uint32_t)(sb / nf);
-    dst[o] = make_uint4(__float_as_uint(cx), __float_as_uint(cy), __float_as_uint(cz), rgba);
+}
+
+// running bounding box of cloud_big: fold the slots k_centroid wrote for a batch (only workgroups that had output)
+__global__ __launch_bounds__(256) void k_cloud_bbox_fold(const float* __restrict__ slots, int nbx, int frames,
+                                                         const uint32_t* __restrict__ n_out, float* __restrict__ partial)
+{
+    __shared__ float mm_lds[6 * 4];
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    const int64_t total = (int64_t)nbx * frames;  // nbx = wave slots per frame
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int f = (int)(i / nbx), bx = (int)(i - (int64_t)f * nbx);
+        if ((int64_t)bx * 64 < (int64_t)n_out[f]) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], slots[i * 6 + a]);
+                hi[a] = fmaxf(hi[a], slots[i * 6 + 3 + a]);
+            }
+        }
+    }
+    block_minmax_store<4>(lo, hi, true, mm_lds, partial + (int64_t)blockIdx.x * 6);
+}
+__global__ void k_cloud_bbox_merge(const float* __restrict__ partial, int n_partial, float* __restrict__ box6)
+{
+    if (threadIdx.x >= 6) return;
+    const int a = threadIdx.x;
+    float v = box6[a];
+    for (int i = 0; i < n_partial; ++i) v = a < 3 ? fminf(v, partial[i * 6 + a]) : fmaxf(v, partial[i * 6 + a]);
+    box6[a] = v;
 }
 
 // =================================================================================================
@@ -2756,10 +2800,16 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             k_centroid<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start,
                 (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, gen_geom, ws.n_out, ws.out_off, v.z_offset,
-                v.passthrough, v.out_base);
+                v.passthrough, v.out_base, (v.cloud_box && !w) ? ws.out_mm : nullptr);
         if (w)
             k_gather_heads<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(v.in, cap, ws.vals[0], ws.vals[1], ws.geom_runs,
                                                                                  ws.n_out, ws.out_off, v.out_base);
+    }
+    if (v.cloud_box && cap > 0 && !use_runs && !w) {
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        const int nbx = cdiv64(cap, kPtThreads) * (kPtThreads / 64);
+        k_cloud_bbox_fold<<<64, 256, 0, s>>>(ws.out_mm, nbx, F, ws.n_out, ws.out_mm_partial);
+        k_cloud_bbox_merge<<<1, 64, 0, s>>>(ws.out_mm_partial, 64, v.cloud_box);
     }
 }
 
