@@ -353,7 +353,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     const char* hb_env = getenv("O3DR_HOST_BATCH_FRAMES");
     if (hb_env && atoi(hb_env) > 0) c->host_batch = atoi(hb_env);
     const char* ru_env = getenv("O3DR_RUNS");
-    if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;
+    if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;       // whole-cloud grids always sort points
+    else if (ru_env && atoi(ru_env) == 2) c->use_runs = 2;  // ... always sort runs (default: decided per cloud on the device)
     if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
     const char* wi_env = getenv("O3DR_WINDOW");
     c->win_enable = (wi_env && atoi(wi_env) == 1) ? 1 : 0;

@@ -444,6 +444,8 @@ __device__ __forceinline__ int64_t scan_row_len(const VoxelGeom* __restrict__ ge
 {
     if (!geom) return L;
     const VoxelGeom g = geom[f];
+    if (pass < 0)  // one entry per run record + 1 (run lengths); nothing for frames that sort points
+        return (g.overflow || g.val_bits == 0u) ? 0 : (int64_t)g.n + 1;
     if (g.overflow || pass >= (int)g.passes) return 0;
     return ((int64_t)1 << g.bpp) * n_tiles;
 }
@@ -1708,12 +1710,14 @@ __global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ seg_off,
                                                     const uint32_t* __restrict__ n_vox,
                                                     uint32_t* __restrict__ seg_start, int buf_sel,
-                                                    uint32_t* __restrict__ head_keys_out)
+                                                    uint32_t* __restrict__ head_keys_out,
+                                                    const VoxelGeom* __restrict__ mode)
 {
     __shared__ uint32_t scan_lds[5];
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom[f];
     if (g.overflow) return;
+    if (mode && mode[f].val_bits == 0u) return;  // this cloud sorts its points, not runs of them (k_run_geom)
     const uint32_t n = g.n;
     const int64_t base = (int64_t)tile * kSegTile;
     if (base >= n) return;
@@ -1744,7 +1748,7 @@ __global__ __launch_bounds__(256) void k_keep_count(const uint32_t* __restrict__
 {
     __shared__ uint32_t lds[4];
     const int f = blockIdx.y, tile = blockIdx.x;
-    if (geom[f].overflow) return;
+    if (geom[f].overflow || geom[f].val_bits != 0u) return;  // (run records: k_keep_count_runs)
     const uint32_t nv = n_vox[f];
     const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
     uint32_t c = 0;
@@ -1768,7 +1772,7 @@ __global__ __launch_bounds__(256) void k_keep_write(const uint32_t* __restrict__
 {
     __shared__ uint32_t scan_lds[5];
     const int f = blockIdx.y, tile = blockIdx.x;
-    if (geom[f].overflow) return;
+    if (geom[f].overflow || geom[f].val_bits != 0u) return;
     const uint32_t nv = n_vox[f];
     const int64_t base = (int64_t)tile * kSegTile;
     if (base >= nv) return;
@@ -1843,22 +1847,17 @@ __global__ __launch_bounds__(256) void k_frame_offsets(const VoxelGeom* __restri
     }
 }
 
-__global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __restrict__ in, int64_t in_fstride,
-                                                         const uint32_t* __restrict__ vals0,
-                                                         const uint32_t* __restrict__ vals1, int64_t cap,
-                                                         const uint32_t* __restrict__ seg_start,
-                                                         const uint32_t* __restrict__ keep_idx,
-                                                         const VoxelGeom* __restrict__ geom,
-                                                         const uint32_t* __restrict__ n_out,
-                                                         const uint64_t* __restrict__ out_off, float z_offset,
-                                                         int passthrough, o3dr_point* __restrict__ out_base,
-                                                         float* __restrict__ out_mm)
+// outputs [256 bx, 256 bx + 256) of frame f
+__device__ __forceinline__ void centroid_block(int64_t bx, int f, const VoxelGeom& g, uint32_t n_o,
+                                               const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                               const uint32_t* __restrict__ vals0, const uint32_t* __restrict__ vals1,
+                                               int64_t cap, const uint32_t* __restrict__ seg_start,
+                                               const uint32_t* __restrict__ keep_idx, const uint64_t* __restrict__ out_off,
+                                               float z_offset, int passthrough, o3dr_point* __restrict__ out_base,
+                                               float* __restrict__ out_mm, int nbx)
 {
-    const int f = blockIdx.y;
-    const int64_t o = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
-    const VoxelGeom g = geom[f];
-    const bool active = o < n_out[f] && (passthrough || g.n != 0);  // g.n == 0: frame taken by the pixel-window path
-    if (!out_mm && !active) return;
+    const int64_t o = bx * kPtThreads + threadIdx.x;
+    const bool active = o < (int64_t)n_o;
     if (__ballot(active) == 0ull) return;  // whole wave idle (k_cloud_bbox_fold skips its slot by the same test)
     uint4 res = make_uint4(0, 0, 0, 0);
     if (active) {
@@ -1905,7 +1904,7 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
         reinterpret_cast<uint4*>(out_base + out_off[f])[o] = res;
     }
     if (out_mm) {  // bounding box of what this wave appended (folded into cloud_big's box by k_cloud_bbox_fold)
-        float* slot = out_mm + (((int64_t)f * gridDim.x + blockIdx.x) * (kPtThreads / 64) + (threadIdx.x >> 6)) * 6;
+        float* slot = out_mm + (((int64_t)f * nbx + bx) * (kPtThreads / 64) + (threadIdx.x >> 6)) * 6;
         const float c3[3] = {__uint_as_float(res.x), __uint_as_float(res.y), __uint_as_float(res.z)};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -1916,6 +1915,35 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __res
                 slot[3 + a] = h;
             }
         }
+    }
+}
+
+// kStride: the grid is smaller than the outputs need and workgroups loop (used where the kernel is launched only in
+// case a cloud took the other sort variant, so that a launch that finds nothing to do costs a few thousand workgroups)
+template <bool kStride>
+__global__ __launch_bounds__(kPtThreads) void k_centroid(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                         const uint32_t* __restrict__ vals0,
+                                                         const uint32_t* __restrict__ vals1, int64_t cap,
+                                                         const uint32_t* __restrict__ seg_start,
+                                                         const uint32_t* __restrict__ keep_idx,
+                                                         const VoxelGeom* __restrict__ geom,
+                                                         const uint32_t* __restrict__ n_out,
+                                                         const uint64_t* __restrict__ out_off, float z_offset,
+                                                         int passthrough, o3dr_point* __restrict__ out_base,
+                                                         float* __restrict__ out_mm, int nbx)
+{
+    const int f = blockIdx.y;
+    const VoxelGeom g = geom[f];
+    // g.n == 0: frame taken by the pixel-window path; val_bits != 0: records are runs (k_centroid_runs writes it)
+    if (!passthrough && (g.n == 0 || g.val_bits != 0u)) return;
+    const uint32_t n_o = n_out[f];
+    if (kStride) {
+        for (int64_t bx = blockIdx.x; bx * kPtThreads < (int64_t)n_o; bx += gridDim.x)
+            centroid_block(bx, f, g, n_o, in, in_fstride, vals0, vals1, cap, seg_start, keep_idx, out_off, z_offset,
+                           passthrough, out_base, out_mm, nbx);
+    } else {
+        centroid_block(blockIdx.x, f, g, n_o, in, in_fstride, vals0, vals1, cap, seg_start, keep_idx, out_off, z_offset,
+                       passthrough, out_base, out_mm, nbx);
     }
 }
 
@@ -1957,14 +1985,20 @@ __global__ void k_cloud_bbox_merge(const float* __restrict__ partial, int n_part
 // gather per point.  Results are bit-identical to the per-point path.
 // =================================================================================================
 __global__ void k_run_geom(const VoxelGeom* __restrict__ geom, const uint32_t* __restrict__ n_runs, int frames,
-                           VoxelGeom* __restrict__ geom_runs)
+                           VoxelGeom* __restrict__ geom_runs, int force_runs)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= frames) return;
     VoxelGeom g = geom[f];
-    g.val_bits = run_start_bits(g.n);  // payload = (first point, length) of the run
-    g.n = g.overflow ? 0u : n_runs[f];
-    g.buf0 = 1;  // the run keys are gathered into buffer 1
+    // Sorting runs pays off when they are long enough (a concatenation of clouds already in voxel order: ~3 points
+    // per run); on raw pixel-order points (~1.4 per run) the extra passes cost more than they save.  Decided here,
+    // on the device: val_bits != 0 marks "records are runs", everything downstream keys off it.
+    const uint32_t nr = n_runs[f];
+    if (g.overflow || (uint64_t)nr * 2u <= (uint64_t)g.n || force_runs) {
+        g.val_bits = run_start_bits(g.n);  // payload = (first point, length) of the run
+        g.n = g.overflow ? 0u : nr;
+        g.buf0 = 1;  // the run keys are gathered into buffer 1
+    }
     geom_runs[f] = g;
 }
 // lengths of the runs in sorted order (then scanned in place): points of voxel v = pref[end] - pref[start]
@@ -1974,7 +2008,7 @@ __global__ __launch_bounds__(256) void k_run_lengths(const uint32_t* __restrict_
 {
     const int f = blockIdx.y;
     const VoxelGeom g = geom_runs[f];
-    if (g.overflow) return;
+    if (g.overflow || g.val_bits == 0u) return;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j > g.n) return;
     uint32_t* out = len_out + (int64_t)f * (cap + 1);
@@ -1995,7 +2029,7 @@ __global__ __launch_bounds__(256) void k_keep_count_runs(const uint32_t* __restr
     __shared__ uint32_t lds[4];
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom_runs[f];
-    if (g.overflow) return;
+    if (g.overflow || g.val_bits == 0u) return;
     const uint32_t nv = n_vox[f];
     const uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
     const uint32_t* lp = len_pref + (int64_t)f * (cap + 1);
@@ -2022,7 +2056,7 @@ __global__ __launch_bounds__(256) void k_keep_write_runs(const uint32_t* __restr
     __shared__ uint32_t scan_lds[5];
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom_runs[f];
-    if (g.overflow) return;
+    if (g.overflow || g.val_bits == 0u) return;
     const uint32_t nv = n_vox[f];
     const int64_t base = (int64_t)tile * kSegTile;
     if (base >= nv) return;
@@ -2053,11 +2087,12 @@ __global__ __launch_bounds__(kPtThreads) void k_centroid_runs(const o3dr_point* 
                                                               o3dr_point* __restrict__ out_base)
 {
     const int f = blockIdx.y;
-    const int64_t o = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
-    if (o >= n_out[f]) return;
+    const VoxelGeom g = geom_runs[f];
+    if (g.val_bits == 0u) return;  // this cloud sorted its points: k_centroid writes it
     const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
     uint4* dst = reinterpret_cast<uint4*>(out_base + out_off[f]);
-    const VoxelGeom g = geom_runs[f];
+    const int64_t o = (int64_t)blockIdx.x * kPtThreads + threadIdx.x;
+    if (o >= n_out[f]) return;
     if (g.overflow) {  // output = input; the caller's z += 500 / z -= 500 still happen around it
         uint4 v = src[o];
         v.z = __float_as_uint((__uint_as_float(v.z) + z_offset) - z_offset);
@@ -2710,9 +2745,10 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 }
                 {
                     ProfScope ps(pf, O3DR_K_SEGMENT, s);
+                    // runs or points?  (decided per cloud on the device; O3DR_RUNS=2 forces runs)
+                    k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs, v.use_runs > 1 ? 1 : 0);
                     k_run_starts<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
-                                                      ws.run_start, 0, ws.keys[1]);  // run keys gathered into buffer 1
-                    k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs);
+                                                      ws.run_start, 0, ws.keys[1], ws.geom_runs);  // run keys -> buffer 1
                 }
             }
             // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
@@ -2752,22 +2788,21 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
             k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, seg_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
-                                              ws.seg_start, -1, nullptr);
+                                              ws.seg_start, -1, nullptr, nullptr);
         }
         if (v.min_points > 1) {
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
                 if (use_runs) {
-                    // points per voxel from a prefix sum over the sorted runs' lengths (stored in keep_idx's
-                    // neighbour array run_len: one pass + one scan instead of walking every voxel's runs twice)
+                    // points per voxel from a prefix sum over the sorted runs' lengths (one pass + one scan instead of
+                    // walking every voxel's runs twice); clouds that sort points skip these on the device
                     k_run_lengths<<<dim3(cdiv64(cap + 1, 256), F), 256, 0, s>>>(ws.vals[0], ws.vals[1], ws.run_start, cap,
                                                                              ws.geom_runs, ws.run_len);
-                    launch_scan(s, ws.run_len, cap + 1, cap + 1, F, nullptr, nullptr, ws.scan_partial);
+                    launch_scan(s, ws.run_len, cap + 1, cap + 1, F, nullptr, nullptr, ws.scan_partial, ws.geom_runs, -1, 0);
                     k_keep_count_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
                                                            n_seg_tiles, ws.seg_cnt);
-                } else
-                    k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, gen_geom, ws.n_vox, v.min_points, n_seg_tiles,
-                                                      ws.seg_cnt);
+                }
+                k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, seg_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -2778,9 +2813,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 if (use_runs)
                     k_keep_write_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
                                                            n_seg_tiles, ws.seg_cnt, ws.keep_idx);
-                else
-                    k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, gen_geom, ws.n_vox, v.min_points, n_seg_tiles,
-                                                      ws.seg_cnt, ws.keep_idx);
+                k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, seg_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt,
+                                                  ws.keep_idx);
             }
             n_keep = ws.n_out;
         }
@@ -2790,17 +2824,25 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         k_frame_offsets<<<1, 256, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc,
                                           v.stats, sort_geom);
     }
+    const int nbx = cdiv64(cap, kPtThreads);
+    if (cap > 0 && use_runs) {
+        ProfScope ps(pf, O3DR_K_CENTROID_RUNS, s);
+        k_centroid_runs<<<dim3(nbx, F), kPtThreads, 0, s>>>(
+            v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, ws.run_start,
+            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.n_out, ws.out_off, v.z_offset, v.out_base);
+    }
     if (cap > 0) {
-        ProfScope ps(pf, use_runs ? O3DR_K_CENTROID_RUNS : O3DR_K_CENTROID, s);
-        if (use_runs)
-            k_centroid_runs<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
-                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, ws.run_start,
-                v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.n_out, ws.out_off, v.z_offset, v.out_base);
+        ProfScope ps(pf, O3DR_K_CENTROID, s);
+        float* out_mm = (v.cloud_box && !w) ? ws.out_mm : nullptr;
+        const uint32_t* keep = (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr;
+        if (use_runs)  // only for clouds k_run_geom left to the point sort: a small looping grid
+            k_centroid<true><<<dim3(nbx < 4096 ? nbx : 4096, F), kPtThreads, 0, s>>>(
+                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom_runs, ws.n_out, ws.out_off,
+                v.z_offset, v.passthrough, v.out_base, out_mm, nbx);
         else
-            k_centroid<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(
-                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start,
-                (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr, gen_geom, ws.n_out, ws.out_off, v.z_offset,
-                v.passthrough, v.out_base, (v.cloud_box && !w) ? ws.out_mm : nullptr);
+            k_centroid<false><<<dim3(nbx, F), kPtThreads, 0, s>>>(
+                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, gen_geom, ws.n_out, ws.out_off,
+                v.z_offset, v.passthrough, v.out_base, out_mm, nbx);
         if (w)
             k_gather_heads<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(v.in, cap, ws.vals[0], ws.vals[1], ws.geom_runs,
                                                                                  ws.n_out, ws.out_off, v.out_base);
