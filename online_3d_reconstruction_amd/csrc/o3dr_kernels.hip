@@ -773,7 +773,8 @@ __device__ __forceinline__ void win_add(const uint4 p, float& sx, float& sy, flo
     sb += (float)(p.w & 255u);
 }
 
-// Search + sums for window radius W (block-uniform: the largest radius any core pixel of the tile needs).
+// Search + sums for window radius W (block-uniform: the largest radius any core pixel of the tile needs; a compile-time
+// constant for W <= 4 so that all window offsets are immediates, a runtime bound above).
 // Looking further than a pixel's own radius is harmless: an equal index anywhere in the tile IS the same voxel.
 template <int W>
 __device__ __forceinline__ void win_heads(const uint32_t* s_key, const uint4* s_pt, int wt, uint32_t (&hk)[4], uint4 (&hc)[4],
@@ -785,7 +786,7 @@ __device__ __forceinline__ void win_heads(const uint32_t* s_key, const uint4* s_
         const int r = r0 + 4 * k;
         const int e0 = (r + wt) * kWinRS + (c + wt);
         const uint32_t key0 = s_key[e0];
-        // any earlier pixel (row-major) with the same index?  independent LDS reads at constant offsets
+        // any earlier pixel (row-major) with the same index?  independent LDS reads
         bool before = false;
 #pragma unroll
         for (int dx = 1; dx <= W; ++dx) before |= s_key[e0 - dx] == key0;
@@ -841,6 +842,55 @@ __device__ __forceinline__ void win_heads(const uint32_t* s_key, const uint4* s_
     }
 }
 
+// the same with a runtime radius (radii above 4: rare, close-range pixels)
+__device__ __noinline__ void win_heads_any(const uint32_t* s_key, const uint4* s_pt, int wt, uint32_t (&hk)[4], uint4 (&hc)[4],
+                                           uint32_t& nh)
+{
+    const int W = wt;
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 4 * k;
+        const int e0 = (r + wt) * kWinRS + (c + wt);
+        const uint32_t key0 = s_key[e0];
+        bool before = false;
+        for (int dx = 1; dx <= W; ++dx) before |= s_key[e0 - dx] == key0;
+        for (int dy = 1; dy <= W; ++dy)
+            for (int dx = -W; dx <= W; ++dx) before |= s_key[e0 - dy * kWinRS + dx] == key0;
+        const bool head = key0 != kNoKey && !before;
+        if (__ballot(head) == 0ull) continue;
+        if (head) {
+            const uint4* pt0 = s_pt + (r * kWinRS + (c + wt));
+            float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
+            uint32_t np = 1;
+            win_add(pt0[0], sx, sy, sz, sr, sg, sb);
+            for (int dx = 1; dx <= W; ++dx)
+                if (s_key[e0 + dx] == key0) {
+                    win_add(pt0[dx], sx, sy, sz, sr, sg, sb);
+                    ++np;
+                }
+            for (int dy = 1; dy <= W; ++dy)
+                for (int dx = -W; dx <= W; ++dx)
+                    if (s_key[e0 + dy * kWinRS + dx] == key0) {
+                        win_add(pt0[dy * kWinRS + dx], sx, sy, sz, sr, sg, sb);
+                        ++np;
+                    }
+            const float nf = (float)np;
+            const float sa = 0.f;
+            const uint32_t rgba = ((uint32_t)(sa / nf) << 24) | ((uint32_t)(sr / nf) << 16) | ((uint32_t)(sg / nf) << 8) |
+                                  (uint32_t)(sb / nf);
+            const uint4 cv = make_uint4(__float_as_uint(sx / nf), __float_as_uint(sy / nf), __float_as_uint(sz / nf - 0.0f), rgba);
+            for (int sl = 0; sl < 4; ++sl)
+                if (nh == (uint32_t)sl) {
+                    hk[sl] = key0;
+                    hc[sl] = cv;
+                }
+            ++nh;
+        }
+    }
+}
+
+// One workgroup per (strip of kWinTY candidate rows, frame): tables, pose and row terms are set up once, then the
+// strip's tiles are walked left to right.
 __global__ __launch_bounds__(256) void k_window_group(ReprojectArgs a, const float* __restrict__ wbase,
                                                       const float* __restrict__ win_c, int tiles_x,
                                                       const VoxelGeom* __restrict__ geom,
@@ -860,131 +910,144 @@ __global__ __launch_bounds__(256) void k_window_group(ReprojectArgs a, const flo
     const int f = blockIdx.y;
     const VoxelGeom g = geom[f];
     if (g.n == 0 || geom_gen[f].n != 0) return;  // empty, or left to the sort-based path by k_window_plan
-    const int ty0 = ((int)blockIdx.x / tiles_x) * kWinTY, tx0 = ((int)blockIdx.x % tiles_x) * kWinTX;
+    const int ty0 = (int)blockIdx.x * kWinTY;
     const uint8_t* disp = a.disp + (int64_t)f * a.disp_fstride;
     const uint8_t* bgr = a.bgr + (int64_t)f * a.bgr_fstride;
-    // ---- radius this tile needs: the largest one over its own (core) pixels
-    {
-        const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-        const int rx = tx0 + c;
-        uint32_t dv[4];
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    // ---- once per strip
+    s_bu[threadIdx.x] = wbase[threadIdx.x];
+    s_bv[threadIdx.x] = wbase[256 + threadIdx.x];
+    lut_alpha[threadIdx.x] = a.lut[threadIdx.x].alpha;
+    lut_z[threadIdx.x] = a.lut[threadIdx.x].z;
+    // the same fp64 operations as the per-pixel form (Q5 * y + Q7, then * 1/w), shared by a row
+    if (threadIdx.x < kWinRows)
+        s_yt[threadIdx.x] = a.Q[5] * (double)(a.bb + (ty0 - kWinHalo + (int)threadIdx.x) * a.jump) + a.Q[7];
+    float m[12];
+    const float* T = a.poses + 16 * (int64_t)f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ry = ty0 + r0 + 4 * k;
-            dv[k] = (ry < a.Ny && rx < a.Nx) ? disp[(int64_t)(a.bb + ry * a.jump) * a.disp_pitch + (a.cs + rx * a.jump)] : 0u;
-        }
-        s_bu[threadIdx.x] = wbase[threadIdx.x];
-        s_bv[threadIdx.x] = wbase[256 + threadIdx.x];
-        lut_alpha[threadIdx.x] = a.lut[threadIdx.x].alpha;
-        lut_z[threadIdx.x] = a.lut[threadIdx.x].z;
-        // the same fp64 operations as the per-pixel form (Q0 * x + Q3, then * 1/w), shared by a column / a row
+    for (int i = 0; i < 12; ++i) m[i] = T[i];
+    const float cu = win_c[2 * f], cv = win_c[2 * f + 1];
+    const bool wide = a.bb >= 1;  // 4-byte colour loads may touch the first byte of the next pixel: needs a margin
+    uint32_t dnext[4];  // core disparities of the next tile (loaded one tile ahead)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ry = ty0 + r0 + 4 * k;
+        dnext[k] = (ry < a.Ny && c < a.Nx) ? disp[(int64_t)(a.bb + ry * a.jump) * a.disp_pitch + (a.cs + c * a.jump)] : 0u;
+    }
+    for (int tile = 0; tile < tiles_x; ++tile) {
+        const int tx0 = tile * kWinTX;
+        // ---- radius this tile needs: the largest one over its own (core) pixels
         if (threadIdx.x < kWinRS)
             s_xt[threadIdx.x] = a.Q[0] * (double)(a.cs + (tx0 - kWinHalo + (int)threadIdx.x) * a.jump) + a.Q[3];
-        else if (threadIdx.x < kWinRS + kWinRows)
-            s_yt[threadIdx.x - kWinRS] = a.Q[5] * (double)(a.bb + (ty0 - kWinHalo + (int)threadIdx.x - kWinRS) * a.jump) + a.Q[7];
-        __syncthreads();
-        const float cu = win_c[2 * f], cv = win_c[2 * f + 1];
+        if (tile == 0) __syncthreads();  // tables
         int wmax = -1;
+        {
+            const int rx = tx0 + c;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ry = ty0 + r0 + 4 * k;
-            if (ry < a.Ny && rx < a.Nx && (double)dv[k] > a.min_disp) {
-                const float fu = cu * s_bu[dv[k]], fv = cv * s_bv[dv[k]];
-                wmax = max(wmax, max((int)(fu + fu * 1e-6f), (int)(fv + fv * 1e-6f)));
+            for (int k = 0; k < 4; ++k) {
+                const int ry = ty0 + r0 + 4 * k;
+                if (ry < a.Ny && rx < a.Nx && (double)dnext[k] > a.min_disp) {
+                    const float fu = cu * s_bu[dnext[k]], fv = cv * s_bv[dnext[k]];
+                    wmax = max(wmax, max((int)(fu + fu * 1e-6f), (int)(fv + fv * 1e-6f)));
+                }
+            }
+            const int rxn = rx + kWinTX;  // prefetch the next tile's core disparities
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ry = ty0 + r0 + 4 * k;
+                dnext[k] = (tile + 1 < tiles_x && ry < a.Ny && rxn < a.Nx)
+                               ? disp[(int64_t)(a.bb + ry * a.jump) * a.disp_pitch + (a.cs + rxn * a.jump)] : 0u;
             }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
         if ((threadIdx.x & 63) == 0) wt_lds[threadIdx.x >> 6] = wmax;
-    }
-    __syncthreads();
-    const int wt = min(max(max(wt_lds[0], wt_lds[1]), max(wt_lds[2], wt_lds[3])), kWinHalo);
-    if (wt < 0) return;  // no valid pixel in the tile (block-uniform)
-    float m[12];
-    const float* T = a.poses + 16 * (int64_t)f;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) m[i] = T[i];
-    // ---- stage the region (tile + halo of wt): voxel index and point of every pixel.
-    //      All loads of a lane's (up to kWinStage) pixels are issued before any is used: one memory round trip.
-    const int RXt = kWinTX + 2 * wt, RYt = kWinTY + 2 * wt;
-    const int n_region = RXt * RYt;
-    {
-        uint32_t dv[kWinStage], col[kWinStage];
-        int ey[kWinStage], ex[kWinStage];
-        bool in[kWinStage];
-        const bool wide = a.bb >= 1;  // 4-byte colour loads may touch the first byte of the next pixel: needs a margin
-#pragma unroll
-        for (int it = 0; it < kWinStage; ++it) {
-            const int i = threadIdx.x + 256 * it;
-            ey[it] = i / RXt;
-            ex[it] = i - ey[it] * RXt;
-            const int ry = ty0 - wt + ey[it], rx = tx0 - wt + ex[it];
-            in[it] = i < n_region && ry >= 0 && ry < a.Ny && rx >= 0 && rx < a.Nx;
-            dv[it] = col[it] = 0u;
-            if (in[it]) {
-                const int y = a.bb + ry * a.jump, x = a.cs + rx * a.jump;
-                const uint8_t* px = bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
-                dv[it] = disp[(int64_t)y * a.disp_pitch + x];
-                if (wide) {
-                    uint32_t v;
-                    __builtin_memcpy(&v, px, 4);  // unaligned dword load: B | G << 8 | R << 16 | (next B) << 24
-                    col[it] = v & 0xffffffu;
-                } else
-                    col[it] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
-            }
+        __syncthreads();
+        const int wt = min(max(max(wt_lds[0], wt_lds[1]), max(wt_lds[2], wt_lds[3])), kWinHalo);
+        if (wt < 0) {  // no valid pixel in the tile (block-uniform)
+            __syncthreads();
+            continue;
         }
+        // ---- stage the region (tile + halo of wt): voxel index and point of every pixel.
+        //      All loads of a lane's pixels are issued before any is used: one memory round trip.
+        const int RXt = kWinTX + 2 * wt, RYt = kWinTY + 2 * wt;
+        const int n_region = RXt * RYt;
+        const uint32_t inv_rx = ((1u << 20) + (uint32_t)RXt - 1u) / (uint32_t)RXt;  // i / RXt == (i * inv_rx) >> 20 for i < 2560
+        {
+            uint32_t dv[kWinStage], col[kWinStage];
+            uint32_t in_mask = 0;
 #pragma unroll
-        for (int it = 0; it < kWinStage; ++it) {
-            if (threadIdx.x + 256 * it < n_region) {
-                uint32_t key = kNoKey;
-                if (in[it] && (double)dv[it] > a.min_disp) {
-                    const double al = lut_alpha[dv[it]];
-                    const float X = (float)(s_xt[ex[it] + kWinHalo - wt] * al + 0.0);
-                    const float Y = (float)(s_yt[ey[it] + kWinHalo - wt] * al + 0.0);
-                    const float Z = lut_z[dv[it]];
-                    const float wx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
-                    const float wy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
-                    const float wz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
-                    const int32_t i0 = (int32_t)floorf(wx * g.inv[0]) - g.min_b[0];
-                    const int32_t i1 = (int32_t)floorf(wy * g.inv[1]) - g.min_b[1];
-                    const int32_t i2 = (int32_t)floorf(wz * g.inv[2]) - g.min_b[2];
-                    key = (uint32_t)i0 + (uint32_t)i1 * g.mul1 + (uint32_t)i2 * g.mul2;
-                    if (ey[it] >= wt)
-                        s_pt[(ey[it] - wt) * kWinRS + ex[it]] = make_uint4(__float_as_uint(wx), __float_as_uint(wy),
-                                                                           __float_as_uint(wz), col[it]);
+            for (int it = 0; it < kWinStage; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                const int ey = (int)(((uint32_t)i * inv_rx) >> 20), ex = i - ey * RXt;
+                const int ry = ty0 - wt + ey, rx = tx0 - wt + ex;
+                dv[it] = col[it] = 0u;
+                if (i < n_region && ry >= 0 && ry < a.Ny && rx >= 0 && rx < a.Nx) {
+                    in_mask |= 1u << it;
+                    const int y = a.bb + ry * a.jump, x = a.cs + rx * a.jump;
+                    const uint8_t* px = bgr + (int64_t)y * a.bgr_pitch + 3 * (int64_t)x;
+                    dv[it] = disp[(int64_t)y * a.disp_pitch + x];
+                    if (wide) {
+                        uint32_t v;
+                        __builtin_memcpy(&v, px, 4);  // unaligned dword load: B | G << 8 | R << 16 | (next B) << 24
+                        col[it] = v & 0xffffffu;
+                    } else
+                        col[it] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
                 }
-                s_key[ey[it] * kWinRS + ex[it]] = key;
+            }
+#pragma unroll
+            for (int it = 0; it < kWinStage; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                if (i < n_region) {
+                    const int ey = (int)(((uint32_t)i * inv_rx) >> 20), ex = i - ey * RXt;
+                    uint32_t key = kNoKey;
+                    if (((in_mask >> it) & 1u) && (double)dv[it] > a.min_disp) {
+                        const double al = lut_alpha[dv[it]];
+                        const float X = (float)(s_xt[ex + kWinHalo - wt] * al + 0.0);
+                        const float Y = (float)(s_yt[ey + kWinHalo - wt] * al + 0.0);
+                        const float Z = lut_z[dv[it]];
+                        const float wx = ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+                        const float wy = ((m[4] * X + m[5] * Y) + m[6] * Z) + m[7];
+                        const float wz = ((m[8] * X + m[9] * Y) + m[10] * Z) + m[11];
+                        const int32_t i0 = (int32_t)floorf(wx * g.inv[0]) - g.min_b[0];
+                        const int32_t i1 = (int32_t)floorf(wy * g.inv[1]) - g.min_b[1];
+                        const int32_t i2 = (int32_t)floorf(wz * g.inv[2]) - g.min_b[2];
+                        key = (uint32_t)i0 + (uint32_t)i1 * g.mul1 + (uint32_t)i2 * g.mul2;
+                        if (ey >= wt)
+                            s_pt[(ey - wt) * kWinRS + ex] = make_uint4(__float_as_uint(wx), __float_as_uint(wy),
+                                                                       __float_as_uint(wz), col[it]);
+                    }
+                    s_key[ey * kWinRS + ex] = key;
+                }
             }
         }
-    }
-    __syncthreads();
-    // ---- heads (lowest row-major pixel of a voxel) add up their voxel
-    uint32_t hk[4];
-    uint4 hc[4];
-    uint32_t nh = 0;
-    switch (wt) {
-        case 0: win_heads<0>(s_key, s_pt, wt, hk, hc, nh); break;
-        case 1: win_heads<1>(s_key, s_pt, wt, hk, hc, nh); break;
-        case 2: win_heads<2>(s_key, s_pt, wt, hk, hc, nh); break;
-        case 3: win_heads<3>(s_key, s_pt, wt, hk, hc, nh); break;
-        case 4: win_heads<4>(s_key, s_pt, wt, hk, hc, nh); break;
-        case 5: win_heads<5>(s_key, s_pt, wt, hk, hc, nh); break;
-        case 6: win_heads<6>(s_key, s_pt, wt, hk, hc, nh); break;
-        case 7: win_heads<7>(s_key, s_pt, wt, hk, hc, nh); break;
-        default: win_heads<8>(s_key, s_pt, wt, hk, hc, nh); break;
-    }
-    // ---- append the tile's voxels to the frame's record list (any order: the indices are unique and get sorted)
-    uint32_t total;
-    const uint32_t pos = block_excl_scan_u32<4>(nh, scan_lds, total);
-    if (threadIdx.x == 0) base_lds = total ? atomicAdd(&n_heads[f], total) : 0u;
-    __syncthreads();
-    const int64_t o = (int64_t)f * cap + base_lds + pos;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if ((uint32_t)k < nh) {
-            keys_out[o + k] = hk[k];
-            reinterpret_cast<uint4*>(cent_out)[o + k] = hc[k];
+        __syncthreads();
+        // ---- heads (lowest row-major pixel of a voxel) add up their voxel
+        uint32_t hk[4];
+        uint4 hc[4];
+        uint32_t nh = 0;
+        switch (wt) {
+            case 0: win_heads<0>(s_key, s_pt, wt, hk, hc, nh); break;
+            case 1: win_heads<1>(s_key, s_pt, wt, hk, hc, nh); break;
+            case 2: win_heads<2>(s_key, s_pt, wt, hk, hc, nh); break;
+            case 3: win_heads<3>(s_key, s_pt, wt, hk, hc, nh); break;
+            case 4: win_heads<4>(s_key, s_pt, wt, hk, hc, nh); break;
+            default: win_heads_any(s_key, s_pt, wt, hk, hc, nh); break;
         }
+        // ---- append the tile's voxels to the frame's record list (any order: the indices are unique and get sorted)
+        uint32_t total;
+        const uint32_t pos = block_excl_scan_u32<4>(nh, scan_lds, total);
+        if (threadIdx.x == 0) base_lds = total ? atomicAdd(&n_heads[f], total) : 0u;
+        __syncthreads();
+        const int64_t o = (int64_t)f * cap + base_lds + pos;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)k < nh) {
+                keys_out[o + k] = hk[k];
+                reinterpret_cast<uint4*>(cent_out)[o + k] = hc[k];
+            }
+        }
+        __syncthreads();  // base_lds, s_key, s_pt are free for the next tile
     }
 }
 
@@ -2690,7 +2753,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         {
             ProfScope ps(pf, O3DR_K_WINDOW, s);
             const int tiles_x = cdiv64(w->a.Nx, kWinTX), tiles_y = cdiv64(w->a.Ny, kWinTY);
-            k_window_group<<<dim3(tiles_x * tiles_y, F), 256, 0, s>>>(w->a, w->wbase, ws.win_c, tiles_x, ws.geom, ws.geom_gen, cap,
+            k_window_group<<<dim3(tiles_y, F), 256, 0, s>>>(w->a, w->wbase, ws.win_c, tiles_x, ws.geom, ws.geom_gen, cap,
                                                                       ws.keys[1], const_cast<o3dr_point*>(v.in), ws.n_runs);
         }
         {
