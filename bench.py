@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--invalid-frac", type=float, default=0.0)
     ap.add_argument("--sor", action="store_true", help="statistical outlier removal on (the reference's full per-frame "
                                                       "path, pose_functions.cpp:1673-1686); off in the headline config")
+    ap.add_argument("--blur-kernel", type=int, default=1, help="> 1: bilateral filter on every disparity image first "
+                    "(--blur_kernel of the reference, README.md:50 uses 30); informational, implies --no-cpu-baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand the library HOST buffers (frames cross PCIe inside the timed region); reported as "
@@ -124,7 +126,8 @@ def main():
     stream = torch.cuda.current_stream()
 
     ctx = o3dr.Context(local_rank, Q=Q, params=o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size,
-                                                          min_points_per_voxel=args.min_points, sor_enable=args.sor), stream=stream)
+                                                          min_points_per_voxel=args.min_points, sor_enable=args.sor,
+                                                          blur_kernel=args.blur_kernel), stream=stream)
     if args.host_inputs:
         disp, bgr, poses = disp_h, bgr_h, poses_h
     else:
@@ -255,7 +258,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: gloo, one GPU)" if rehearsal else ""),
         "config": {"workload": f"synthetic {args.cols}x{args.rows} dense stereo, jump_pixels {args.jump_pixels}, "
                                f"{F} frames/GPU, voxel_size {args.voxel_size}, min_points_per_voxel {args.min_points}, "
-                               f"SOR {'on' if args.sor else 'off'}, frames resident in HBM (BASELINE.json configs[1])",
+                               f"SOR {'on' if args.sor else 'off'}, " + (f"blur_kernel {args.blur_kernel}, " if args.blur_kernel > 1 else "") + f"frames resident in HBM (BASELINE.json configs[1])",
                    "frames_per_gpu": F, "rows": args.rows, "cols": args.cols, "jump_pixels": args.jump_pixels,
                    "voxel_size": args.voxel_size, "parallelism": f"frame-sharded x{world}"},
         "mpoints_per_sec_into_global_cloud": round(m1_total * args.steps / dt / 1e6, 2),
@@ -269,7 +272,7 @@ def main():
                  "frames_on_window_path_per_step": int(win_frames)},
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
         nf = min(args.cpu_frames, F)
         v7, t7 = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, args.cpu_threads, nf, args.sor)
         n1 = min(100, F)

@@ -79,7 +79,7 @@ def _read_ply(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--reference_fanout"]])
+@pytest.mark.parametrize("extra", [[], ["--reference_fanout"], ["--blur_kernel", "30"], ["--blur_kernel", "5", "--reference_fanout"]])
 def test_cli_runs_config1_frames_and_matches_oracle(tmp_path, orc, Q, extra):
     from online_3d_reconstruction_amd import synth
     assert os.path.exists(POSE_BIN), "run `make` / __graft_entry__.build() first"
@@ -94,9 +94,12 @@ def test_cli_runs_config1_frames_and_matches_oracle(tmp_path, orc, Q, extra):
     assert "1247 could not read rgb image" in res.stdout and "Point Cloud Creation time" in res.stdout
     got = _read_ply(tmp + "/output/cloud.ply")
 
+    bk = int(extra[extra.index("--blur_kernel") + 1]) if "--blur_kernel" in extra else 1  # README.md:50 runs with 30
     clouds = []
     for name in ("1248", "1249"):
         disp, bgr = load_frame(name)
+        if bk > 1:
+            disp = orc.blur_disparity(disp, bk)
         _, row = pose_row_for_image(int(name))
         T = synth.generate_tmat(row[3:6], row[6:10])
         clouds.append(orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=15)[0])
