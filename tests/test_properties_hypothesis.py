@@ -33,7 +33,7 @@ def clouds(draw, max_n=400):
     return pts, np.float32(leaf)
 
 
-SETTINGS = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+SETTINGS = dict(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
 @settings(**SETTINGS)
