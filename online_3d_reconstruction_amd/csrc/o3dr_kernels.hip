@@ -1222,6 +1222,50 @@ __global__ __launch_bounds__(kPtThreads) void k_voxel_keys(const o3dr_point* __r
     }
 }
 
+// k_voxel_keys + the head count of k_run_heads(buf_sel 0) in one read of the points (run-compressed calls):
+// a point starts a run iff its index differs from its predecessor's (or the packed length would overflow).
+// One workgroup = one segment tile (kSegTile points, 4 sub-rows of 256 consecutive points).
+__device__ __forceinline__ uint32_t voxel_key_of(const uint4 v, const VoxelGeom& g, float z_offset)
+{
+    const float x = __uint_as_float(v.x), y = __uint_as_float(v.y), z = __uint_as_float(v.z) + z_offset;
+    const int32_t i0 = (int32_t)floorf(x * g.inv[0]) - g.min_b[0];
+    const int32_t i1 = (int32_t)floorf(y * g.inv[1]) - g.min_b[1];
+    const int32_t i2 = (int32_t)floorf(z * g.inv[2]) - g.min_b[2];
+    return (uint32_t)i0 + (uint32_t)i1 * g.mul1 + (uint32_t)i2 * g.mul2;
+}
+__global__ __launch_bounds__(256) void k_voxel_keys_heads(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                          const VoxelGeom* __restrict__ geom, float z_offset, int64_t cap,
+                                                          uint32_t* __restrict__ keys, int n_tiles,
+                                                          uint32_t* __restrict__ seg_cnt)
+{
+    static_assert(kSegTile == 4 * 256, "one workgroup per segment tile");
+    __shared__ uint32_t lds[4];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const VoxelGeom g = geom[f];
+    if (g.overflow) return;
+    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+    uint32_t* dst = keys + (int64_t)f * cap;
+    const uint32_t split = run_split_mask(run_start_bits(g.n));
+    const int64_t base = (int64_t)tile * kSegTile;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        uint32_t key = 0;
+        if (i < g.n) {
+            key = voxel_key_of(src[i], g, z_offset);
+            dst[i] = key;
+        }
+        uint32_t prev = __shfl_up(key, 1, 64);
+        if ((threadIdx.x & 63) == 0 && i > 0 && i < g.n) prev = voxel_key_of(src[i - 1], g, z_offset);  // previous wave's point
+        if (i < g.n) c += (((uint32_t)i & split) == 0u || key != prev) ? 1u : 0u;
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[(int64_t)f * n_tiles + tile] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
 // Single-pass variant: the same index computation, plus per-workgroup digit histograms for EVERY pass
 // of the frame's sort plan (the digits do not depend on record order), written as partial tables
 // (no global atomics) and folded by k_digit_starts.
@@ -2792,16 +2836,16 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         } else {
             {
                 ProfScope ps(pf, O3DR_K_KEYGEN, s);
-                k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, gen_geom,
-                                                                                        v.z_offset, cap, ws.keys[0]);
+                if (use_runs)  // indices and, in the same read, how many runs of equal indices start in every tile
+                    k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
+                                                                           ws.keys[0], n_seg_tiles, ws.seg_cnt);
+                else
+                    k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, gen_geom,
+                                                                                            v.z_offset, cap, ws.keys[0]);
             }
             if (use_runs) {
                 // runs of consecutive equal indices -> (run key, run id) records in buffer 1
                 const dim3 rgrid(n_seg_tiles, F);
-                {
-                    ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                    k_run_heads<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, 0);
-                }
                 {
                     ProfScope ps(pf, O3DR_K_OTHER, s);
                     launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_runs, nullptr, ws.scan_partial);
