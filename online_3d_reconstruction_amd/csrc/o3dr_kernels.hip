@@ -1411,6 +1411,46 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     }
 }
 
+// k_voxel_keys + k_radix_hist of pass 0 in one read of the points (per-frame grids of the batched path): one
+// workgroup = one sort tile; the indices are written for the scatter, their lowest digit is counted on the way.
+__global__ __launch_bounds__(kSortThreads) void k_voxel_keys_hist0(const o3dr_point* __restrict__ in, int64_t in_fstride,
+                                                                   const VoxelGeom* __restrict__ geom, float z_offset,
+                                                                   int64_t cap, uint32_t* __restrict__ keys, int n_tiles,
+                                                                   uint32_t* __restrict__ hist)
+{
+    constexpr int kSub = 4;
+    __shared__ uint32_t h[kSub * kSortWaves * kMaxRadix];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const VoxelGeom g = geom[f];
+    if (g.overflow) return;
+    const uint32_t n = g.n;
+    const int64_t base = (int64_t)tile * kSortTile;  // (tiles past the end still write their zeros: the scan reads them)
+    const int bins = 1 << g.bpp;
+    const uint32_t dmask = (uint32_t)bins - 1u;
+    for (int i = threadIdx.x; i < kSub * kSortWaves * kMaxRadix; i += kSortThreads) h[i] = 0;
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(in + (int64_t)f * in_fstride);
+    uint32_t* dst = keys + (int64_t)f * cap;
+    uint32_t* hw = h + (((threadIdx.x >> 6) * kSub) + (threadIdx.x & (kSub - 1))) * kMaxRadix;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = base + (int64_t)r * kSortThreads + threadIdx.x;
+        if (i < n) {
+            const uint32_t key = voxel_key_of(src[i], g, z_offset);
+            dst[i] = key;
+            atomicAdd(&hw[key & dmask], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* hd = hist + (int64_t)f * kMaxRadix * n_tiles;
+    for (int dgt = threadIdx.x; dgt < bins; dgt += kSortThreads) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int ww = 0; ww < kSub * kSortWaves; ++ww) t += h[ww * kMaxRadix + dgt];
+        hd[(int64_t)dgt * n_tiles + tile] = t;
+    }
+}
+
 // Chained-scan ("look-back") state of the single-pass variant: one 64-bit word per (tile, digit),
 //   [63:42] epoch of the launch that wrote it   [41:40] 1 = tile's own count, 2 = inclusive prefix
 //   [39:0]  value.
@@ -2783,6 +2823,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     // what the per-point kernels of the sort-based path see: frames on the window path have n = 0 there
     const VoxelGeom* gen_geom = w ? ws.geom_gen : ws.geom;
     const VoxelGeom* seg_geom = w ? ws.geom_gen : sort_geom;
+    // plain point sort (per-frame grids of a batch): the index kernel also counts the first pass's digits
+    const bool fuse_hist0 = !use_runs && !w && !ws.single_pass && !getenv("O3DR_NO_FUSE_HIST0");
     if (w) {
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -2839,6 +2881,9 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 if (use_runs)  // indices and, in the same read, how many runs of equal indices start in every tile
                     k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
                                                                            ws.keys[0], n_seg_tiles, ws.seg_cnt);
+                else if (fuse_hist0)  // ... and the histogram of the first radix pass
+                    k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, gen_geom, v.z_offset, cap, ws.keys[0],
+                                                                     n_sort_tiles, ws.hist);
                 else
                     k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, gen_geom,
                                                                                             v.z_offset, cap, ws.keys[0]);
@@ -2861,7 +2906,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
             const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
             for (int pass = 0; pass < kMaxPasses; ++pass) {
-                {
+                if (!(pass == 0 && fuse_hist0)) {
                     ProfScope ps(pf, O3DR_K_SORT_HIST, s);
                     k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, pass, n_sort_tiles,
                                                               ws.hist);

@@ -485,7 +485,7 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"O3DR_SCATTER": "ballot"}, {"O3DR_SORT": "lookback"}, {"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"},
-                                 {"O3DR_NO_QLUT": "1"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_WINDOW": "1"}, {"O3DR_NO_CLOUD_BOX": "1"}])
+                                 {"O3DR_NO_QLUT": "1"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_WINDOW": "1"}, {"O3DR_NO_CLOUD_BOX": "1"}, {"O3DR_NO_FUSE_HIST0": "1"}])
 def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     """the A/B variants kept behind environment switches (ballot-matching scatter, look-back single-pass
     sort, per-point instead of per-run merge, general Q product, small launch groups) give the same bits"""
