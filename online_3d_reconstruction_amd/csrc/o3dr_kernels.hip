@@ -1825,10 +1825,27 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter_lane(uint32_t* _
 // =================================================================================================
 
 // buf_sel < 0: the frame's sorted buffer; 0/1: that buffer as is (runs of an UNSORTED sequence)
+// four consecutive records of a segment tile per lane (one 16-byte load when the frame base allows it) and the key
+// just before them: lane order = record order, so one workgroup scan per tile ranks the run heads
+__device__ __forceinline__ void load_seg_keys(const uint32_t* __restrict__ k, int64_t i0, uint32_t n, bool vec, uint32_t kk[4],
+                                              uint32_t& prev)
+{
+    if (vec && i0 + 3 < (int64_t)n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(k + i0);
+        kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kk[q] = (i0 + q < (int64_t)n) ? k[i0 + q] : 0u;
+    }
+    prev = __shfl_up(kk[3], 1, 64);
+    if ((threadIdx.x & 63) == 0) prev = (i0 > 0 && i0 < (int64_t)n) ? k[i0 - 1] : 0u;  // previous wave's / tile's last key
+}
+
 __global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ keys1,
                                                    int64_t cap, const VoxelGeom* __restrict__ geom, int n_tiles,
                                                    uint32_t* __restrict__ seg_cnt, int buf_sel)
 {
+    static_assert(kSegTile == 4 * 256, "four records per lane");
     __shared__ uint32_t lds[4];
     const int f = blockIdx.y, tile = blockIdx.x;
     const VoxelGeom g = geom[f];
@@ -1838,12 +1855,14 @@ __global__ __launch_bounds__(256) void k_run_heads(const uint32_t* __restrict__ 
     // forming runs of points (buf_sel 0): also cut where the packed length would overflow
     const uint32_t split = buf_sel == 0 ? run_split_mask(run_start_bits(n)) : 0xffffffffu;
     uint32_t c = 0;
-    const int64_t base = (int64_t)tile * kSegTile;
-    if (base < n) {
+    const int64_t i0 = (int64_t)tile * kSegTile + threadIdx.x * 4;
+    if ((int64_t)tile * kSegTile < n) {
+        uint32_t kk[4], prev;
+        load_seg_keys(k, i0, n, ((((int64_t)f * cap) & 3) == 0), kk, prev);
 #pragma unroll
-        for (int j = 0; j < kSegTile / 256; ++j) {
-            const int64_t i = base + j * 256 + threadIdx.x;
-            if (i < n) c += (((uint32_t)i & split) == 0u || k[i] != k[i - 1]) ? 1u : 0u;
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + q;
+            if (i < n) c += (((uint32_t)i & split) == 0u || kk[q] != (q ? kk[q - 1] : prev)) ? 1u : 0u;
         }
     }
     c = wave_sum_u32(c);
@@ -1871,19 +1890,28 @@ __global__ __launch_bounds__(256) void k_run_starts(const uint32_t* __restrict__
     const uint32_t* k = (buf_sel < 0 ? sorted_buf(g, keys0, keys1) : (buf_sel ? keys1 : keys0)) + (int64_t)f * cap;
     uint32_t* ss = seg_start + (int64_t)f * (cap + 1);
     if (tile == 0 && threadIdx.x == 0) ss[n_vox[f]] = n;  // sentinel: end of the last run
-    uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
+    const uint32_t off = seg_off[(int64_t)f * n_tiles + tile];
     const uint32_t split = buf_sel == 0 ? run_split_mask(run_start_bits(n)) : 0xffffffffu;
-    // 4 sub-rows of 256 consecutive records keep (sub-row, lane) order = sorted order
-    for (int j = 0; j < kSegTile / 256; ++j) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        const bool head = (i < n) && (((uint32_t)i & split) == 0u || k[i] != k[i - 1]);
-        uint32_t total;
-        const uint32_t pos = block_excl_scan_u32<4>(head ? 1u : 0u, scan_lds, total);
-        if (head) {
-            ss[off + pos] = (uint32_t)i;
-            if (head_keys_out) head_keys_out[(int64_t)f * cap + off + pos] = k[i];  // run key = index of its first point
+    const int64_t i0 = base + threadIdx.x * 4;
+    uint32_t kk[4], prev;
+    load_seg_keys(k, i0, n, ((((int64_t)f * cap) & 3) == 0), kk, prev);
+    bool head[4];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = i0 + q;
+        head[q] = (i < n) && (((uint32_t)i & split) == 0u || kk[q] != (q ? kk[q - 1] : prev));
+        cnt += head[q] ? 1u : 0u;
+    }
+    uint32_t total;
+    uint32_t pos = off + block_excl_scan_u32<4>(cnt, scan_lds, total);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (head[q]) {
+            ss[pos] = (uint32_t)(i0 + q);
+            if (head_keys_out) head_keys_out[(int64_t)f * cap + pos] = kk[q];  // run key = index of its first point
+            ++pos;
         }
-        off += total;
     }
 }
 
