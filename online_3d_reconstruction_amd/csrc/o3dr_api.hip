@@ -192,7 +192,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_geomg = off; off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_winc = off;  off += align256((size_t)F * 2 * sizeof(float));
         size_t o_omm = off;   off += align256((E / 64 + 8 * (size_t)F + 64) * 6 * sizeof(float));
-        size_t o_ommp = off;  off += align256(64 * 6 * sizeof(float));
+        size_t o_ommp = off;  off += align256((size_t)kBoxFoldBlocks * 6 * sizeof(float));
         CHK(dev_ensure(c, c->ws_block, off));
         char* base = (char*)c->ws_block.p;
         Workspace& w = c->ws;

@@ -122,7 +122,7 @@ struct Workspace {
     VoxelGeom* geom_gen = nullptr;   // frames: geom with n = 0 for frames taken by the pixel-window path
     float* win_c = nullptr;          // frames*2: per-frame factors on the window table (k_window_plan)
     float* out_mm = nullptr;         // frames*ceil(cap/256)*4*6: bounding boxes of what k_centroid's waves appended
-    float* out_mm_partial = nullptr; // 64*6
+    float* out_mm_partial = nullptr; // kBoxFoldBlocks*6
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
     int64_t mm_stride = 0;         // slots per frame
     uint32_t* n_valid = nullptr;   // frames     points per frame after A1
@@ -194,6 +194,7 @@ struct WindowPlan {
     float err_budget;     // allowed fp32 rounding error of a world coordinate (metres)
     const uint32_t* n_kp; // zeros
 };
+constexpr int kBoxFoldBlocks = 1024;  // workgroups (and partial boxes) of the running-bounding-box fold
 constexpr int kWinHalo = 8;        // largest window radius (candidates) the tile kernel supports
 constexpr float kWinCMax = 1.9f;   // largest per-frame factor on the table (>= 1.06 * sqrt(3) * 1.005 + 0.05)
 void launch_frame_bbox(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, uint32_t* tile_cnt,

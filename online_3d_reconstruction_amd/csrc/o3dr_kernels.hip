@@ -2142,13 +2142,13 @@ __global__ __launch_bounds__(256) void k_cloud_bbox_fold(const float* __restrict
     }
     block_minmax_store<4>(lo, hi, true, mm_lds, partial + (int64_t)blockIdx.x * 6);
 }
-__global__ void k_cloud_bbox_merge(const float* __restrict__ partial, int n_partial, float* __restrict__ box6)
+__global__ __launch_bounds__(384) void k_cloud_bbox_merge(const float* __restrict__ partial, int n_partial, float* __restrict__ box6)
 {
-    if (threadIdx.x >= 6) return;
-    const int a = threadIdx.x;
-    float v = box6[a];
-    for (int i = 0; i < n_partial; ++i) v = a < 3 ? fminf(v, partial[i * 6 + a]) : fmaxf(v, partial[i * 6 + a]);
-    box6[a] = v;
+    const int a = threadIdx.x >> 6, lane = threadIdx.x & 63;  // one wave per component (min x,y,z, max x,y,z)
+    float v = a < 3 ? __builtin_inff() : -__builtin_inff();
+    for (int i = lane; i < n_partial; i += 64) v = a < 3 ? fminf(v, partial[i * 6 + a]) : fmaxf(v, partial[i * 6 + a]);
+    v = a < 3 ? wave_min_f32(v) : wave_max_f32(v);
+    if (lane == 0) box6[a] = a < 3 ? fminf(box6[a], v) : fmaxf(box6[a], v);
 }
 
 // =================================================================================================
@@ -3030,8 +3030,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     if (v.cloud_box && cap > 0 && !use_runs && !w) {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         const int nbx = cdiv64(cap, kPtThreads) * (kPtThreads / 64);
-        k_cloud_bbox_fold<<<64, 256, 0, s>>>(ws.out_mm, nbx, F, ws.n_out, ws.out_mm_partial);
-        k_cloud_bbox_merge<<<1, 64, 0, s>>>(ws.out_mm_partial, 64, v.cloud_box);
+        k_cloud_bbox_fold<<<kBoxFoldBlocks, 256, 0, s>>>(ws.out_mm, nbx, F, ws.n_out, ws.out_mm_partial);
+        k_cloud_bbox_merge<<<1, 384, 0, s>>>(ws.out_mm_partial, kBoxFoldBlocks, v.cloud_box);
     }
 }
 
