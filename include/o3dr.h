@@ -2,8 +2,9 @@
  * o3dr.h — C ABI of libo3dr, the MI355X (gfx950) implementation of the per-frame
  * reconstruction hot path of pk17r/online_3d_reconstruction:
  *
- *   disparity image -> 3D back-projection through Q -> rigid transform into the
- *   world frame -> voxel-grid downsample -> accumulate -> 2.5-D global merge.
+ *   disparity image [-> bilateral filter] -> 3D back-projection through Q -> rigid
+ *   transform into the world frame [-> statistical outlier removal] -> voxel-grid
+ *   downsample -> accumulate -> 2.5-D global merge.
  *
  * The reference has no FFI/plugin interface; the seam is four `Pose` member
  * functions plus the fan-out/accumulate loop around them.  Every entry point
@@ -19,7 +20,8 @@
  *     parameter arrays (Q, poses of the single-frame calls, leaf) are always
  *     host pointers; the batched `o3dr_accumulate_frames` takes its pose array
  *     in `mem` like the images.
- *   - images are OpenCV-layout: disparity CV_8UC1 row-major with a byte pitch,
+ *   - images are OpenCV-layout: disparity CV_8UC1 row-major with a byte pitch (CV_64F
+ *     with o3dr_params.disparity_f64: pitch and frame stride stay in bytes),
  *     colour CV_8UC3 interleaved B,G,R with a byte pitch (pose_functions.cpp:526,548).
  *   - points are 16 bytes: x,y,z float + packed colour (a<<24|r<<16|g<<8|b), the
  *     same packing pose_functions.cpp:1120-1121 stores in PointXYZRGB::rgb.
