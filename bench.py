@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand the library HOST buffers (frames cross PCIe inside the timed region); reported as "
                          "metric frames_per_sec_pcie_inclusive, never the headline value")
+    ap.add_argument("--pinned", action="store_true", help="with --host-inputs: page-locked host buffers")
     ap.add_argument("--cpu-frames", type=int, default=200)
     ap.add_argument("--cpu-threads", type=int, default=7)
     ap.add_argument("--gen-workers", type=int, default=min(16, os.cpu_count() or 1))
@@ -128,7 +129,11 @@ def main():
     ctx = o3dr.Context(local_rank, Q=Q, params=o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size,
                                                           min_points_per_voxel=args.min_points, sor_enable=args.sor,
                                                           blur_kernel=args.blur_kernel), stream=stream)
-    if args.host_inputs:
+    if args.host_inputs and args.pinned:
+        disp = torch.from_numpy(disp_h).pin_memory()
+        bgr = torch.from_numpy(bgr_h).pin_memory()
+        poses = torch.from_numpy(poses_h).pin_memory()
+    elif args.host_inputs:
         disp, bgr, poses = disp_h, bgr_h, poses_h
     else:
         disp = torch.from_numpy(disp_h).to(dev)
