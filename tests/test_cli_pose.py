@@ -79,7 +79,8 @@ def _read_ply(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--reference_fanout"], ["--blur_kernel", "30"], ["--blur_kernel", "5", "--reference_fanout"]])
+@pytest.mark.parametrize("extra", [[], ["--reference_fanout"], ["--blur_kernel", "30"], ["--blur_kernel", "5", "--reference_fanout"],
+                                   ["--sor", "1"], ["--sor", "1", "--blur_kernel", "5", "--reference_fanout"]])
 def test_cli_runs_config1_frames_and_matches_oracle(tmp_path, orc, Q, extra):
     from online_3d_reconstruction_amd import synth
     assert os.path.exists(POSE_BIN), "run `make` / __graft_entry__.build() first"
@@ -102,7 +103,12 @@ def test_cli_runs_config1_frames_and_matches_oracle(tmp_path, orc, Q, extra):
             disp = orc.blur_disparity(disp, bk)
         _, row = pose_row_for_image(int(name))
         T = synth.generate_tmat(row[3:6], row[6:10])
-        clouds.append(orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=15)[0])
+        if "--sor" in extra:  # the reference's literal per-frame path: A1 -> A2 -> outlier removal -> voxel grid
+            world = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=15), T)
+            kept, _ = orc.statistical_outlier_removal(world)
+            clouds.append(orc.downsample_pt_cloud(kept, 0.05, False, 1)[0])
+        else:
+            clouds.append(orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=15)[0])
     ref, _ = orc.downsample_pt_cloud(np.concatenate(clouds), 0.05, True, 1)
     assert len(got) == len(ref)
     for ax in "xyz":
