@@ -564,7 +564,9 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
 // take the sort-based path inside the same launches.
 static bool window_plan(o3dr_ctx* c, const GridShape& g, int rows, int cols, float leaf, WindowPlan* w)
 {
-    if (!c->win_enable || !c->q_lut_on || c->single_pass || c->params.dont_downsample || c->params.jump_pixels < 1) return false;
+    if (!c->win_enable || !c->q_lut_on || c->single_pass || c->params.dont_downsample || c->params.jump_pixels < 1 ||
+        c->params.disparity_f64)  // (the depth-level argument needs integer disparities)
+        return false;
     const QLutEntry* lut = (const QLutEntry*)c->misc_host_lut;
     const double* Q = c->Q;
     if (Q[0] == 0.0 || Q[5] == 0.0 || !(leaf > 0.f)) return false;
