@@ -838,3 +838,52 @@ def test_A7_dont_downsample_accumulates_raw_points(ctx, orc):
         assert_points_equal(ctx.finalize(), ref, "cloud_small = cloud_big")
     finally:
         ctx.set_params(_params(jump_pixels=5, voxel_size=0.05))
+
+
+def test_error_behaviour_of_the_c_abi(Q, frame_1249):
+    """every failure returns a negative code, leaves *n_out at 0 ("output cloud left empty", pose.cpp:620-635) and
+    explains itself through o3dr_last_error; a context stays usable afterwards"""
+    import ctypes as C
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import _lib as L
+    lib = o3dr.load_library()
+    disp, bgr = frame_1249
+    T = np.eye(4, dtype=np.float32).reshape(16)
+    out = np.zeros(800000, o3dr.POINT)
+    n = C.c_int64(123)
+    st = C.c_uint32(7)
+
+    def call(h, d=disp, b=bgr, dp=1280, bp=3840, rows=720, cols=1280, cap=len(out), mem=L.MEM_HOST, o=out):
+        n.value = 123
+        return lib.o3dr_create_and_transform_pt_cloud(h, d.ctypes.data if d is not None else None, dp,
+                                                      b.ctypes.data if b is not None else None, bp, rows, cols, T.ctypes.data,
+                                                      None, 0, o.ctypes.data if o is not None else None, cap, C.byref(n),
+                                                      C.byref(st), mem)
+
+    assert call(None) == L.ERR_INVALID_ARG and n.value == 0                       # no context
+    assert b"ctx is NULL" in lib.o3dr_last_error()
+    with o3dr.Context(0) as c:
+        h = c._h
+        assert call(h) == L.ERR_NOT_CONFIGURED and n.value == 0                   # camera not set
+        c.set_camera(Q)
+        c.set_params(o3dr.Params(jump_pixels=1, voxel_size=0.05))
+        assert call(h, d=None) == L.ERR_INVALID_ARG and n.value == 0              # NULL image
+        assert call(h, dp=1279) == L.ERR_INVALID_ARG and n.value == 0             # pitch smaller than a row
+        assert call(h, rows=0) == L.ERR_INVALID_ARG and n.value == 0
+        assert call(h, mem=5) == L.ERR_INVALID_ARG and n.value == 0
+        assert call(h, o=None) == L.ERR_INVALID_ARG and n.value == 0
+        assert call(h, cap=10) == L.ERR_CAPACITY and n.value == 0                 # host output too small for the result
+        assert b"too small" in lib.o3dr_last_error()
+        bad = o3dr.Params(jump_pixels=-1)
+        with pytest.raises(o3dr.O3drError) as e:
+            c.set_params(bad)
+        assert e.value.code == L.ERR_INVALID_ARG
+        with pytest.raises(o3dr.O3drError):
+            c.set_params(o3dr.Params(voxel_size=0.0))
+        # still usable, and correct
+        assert call(h) == L.OK and n.value > 0 and st.value == 0
+        c.cloudBigReset()
+        with pytest.raises(o3dr.O3drError):                                       # frame stride smaller than a frame
+            L.check(lib.o3dr_accumulate_frames(h, disp.ctypes.data, 100, 1280, bgr.ctypes.data, 3840 * 720, 3840, 720, 1280,
+                                               T.ctypes.data, 1, L.MEM_HOST))
+        assert c.cloudBigSize() == (0, 0)
