@@ -287,6 +287,15 @@ def main():
                                             f"{args.cpu_threads} frame-parallel threads as pose.cpp:392-413, then the combined "
                                             f"merge), {t7:.1f} s; single thread: {v1:.3f} frames/s on {n1} frames",
                                   "single_thread_value": round(v1, 3), "host_cores": os.cpu_count()}
+        # all cores of this host (frame-parallel part only scales; the merge is one thread, as in
+        # the reference), plus what the host is
+        try:
+            n_all = max(1, min(len(os.sched_getaffinity(0)), nf))
+            va, ta = cpu_baseline(disp_h, bgr_h, poses_h, Q, args.voxel_size, args.jump_pixels, n_all, nf, args.sor)
+            model = next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "?")
+            result["cpu_baseline"].update({"all_cores_value": round(va, 3), "all_cores_threads": n_all, "cpu_model": model})
+        except Exception:
+            pass
     if rank == 0:
         print(json.dumps(result), flush=True)
     ctx.close()
