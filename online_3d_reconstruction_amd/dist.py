@@ -80,13 +80,16 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
     rank = dist.get_rank(group)
     cdev = comm_device if comm_device is not None else device
     mn, mx, n_local = ctx.cloudBigBBox()
-    box = torch.tensor(np.concatenate([mn, -mx]), dtype=torch.float32, device=cdev)
-    dist.all_reduce(box, op=dist.ReduceOp.MIN, group=group)  # min of mins, min of (-max) = -(max of maxes)
-    box = box.cpu().numpy()
-    gmin, gmax = box[:3].copy(), (-box[3:]).copy()
-    tot = torch.tensor([n_local], dtype=torch.int64, device=cdev)
-    dist.all_reduce(tot, group=group)
-    total = int(tot.item())
+    # one small all-gather carries every rank's box and count (instead of two all-reduces): 6 floats + the count
+    # split into two 24-bit halves, exact in fp32
+    mine_hdr = torch.tensor(np.concatenate([mn, mx, [float(n_local & 0xFFFFFF), float(n_local >> 24)]]), dtype=torch.float32,
+                            device=cdev)
+    hdr = torch.empty(world * 8, dtype=torch.float32, device=cdev)  # (flat: gloo wants the concatenated shape)
+    dist.all_gather_into_tensor(hdr, mine_hdr, group=group)
+    hdr = hdr.cpu().numpy().reshape(world, 8)
+    gmin = hdr[:, 0:3].min(axis=0).astype(np.float32)  # empty ranks contribute (+inf, -inf)
+    gmax = hdr[:, 3:6].max(axis=0).astype(np.float32)
+    total = int(sum(int(h[6]) + (int(h[7]) << 24) for h in hdr))
     if total == 0:
         return torch.empty((0, 4), dtype=torch.int32, device=device), 0
     counts, status = ctx.cloudBigPartition(gmin, gmax, world)
@@ -98,9 +101,9 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
         # send straight out of cloud_big, receive straight into the library's second cloud buffer
         send = ctx.cloudBigView()
         sc = torch.tensor(counts, dtype=torch.int64, device=device)
-        rc = torch.empty(world, dtype=torch.int64, device=device)
-        dist.all_to_all_single(rc, sc, group=group)
-        recv_counts = [int(v) for v in rc.tolist()]
+        allc = torch.empty(world * world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allc, sc, group=group)   # row s = what rank s sends to everybody
+        recv_counts = [int(v) for v in allc.view(world, world)[:, rank].tolist()]
         n_recv = sum(recv_counts)
         recv = ctx.cloudBigRecvBuffer(n_recv)
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
