@@ -392,6 +392,15 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
     const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
     ProfScope ps(pf, O3DR_K_OTHER, s);
     k_voxel_geom<<<1, 256, 0, s>>>(ws.mm, ws.mm_stride, 1, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset, ws.geom);
+    if (n_parts <= kMaxRadix && !getenv("O3DR_PARTITION_SORT")) {
+        // direct form: count per (part, tile), scan, move the points (two reads and one write of the cloud)
+        k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
+        k_part_count<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist);
+        launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, 0, n_sort_tiles);
+        k_part_move<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist, out);
+        k_part_counts_scanned<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.hist, ws.geom, n_parts, n_sort_tiles, counts_dev, overflow_dev);
+        return;
+    }
     k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), 1), kPtThreads, 0, s>>>(v.in, 0, ws.geom, v.z_offset, cap, ws.keys[0]);
     k_part_ids<<<cdiv64(cap, 256), 256, 0, s>>>(ws.keys[0], ws.geom, n_parts);
     k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);

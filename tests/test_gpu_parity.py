@@ -300,10 +300,12 @@ def test_full_size_properties(ctx):
 
 
 # ---- multi-GPU merge pieces on one GPU: virtual ranks, exchange done by hand ---------------------------
-@pytest.mark.parametrize("world", [2, 5])
-def test_partitioned_merge_virtual_ranks(Q, orc, world):
+@pytest.mark.parametrize("world,sort_form", [(2, False), (5, False), (3, True), (8, False)])
+def test_partitioned_merge_virtual_ranks(Q, orc, world, sort_form, monkeypatch):
     """cloud_big_bbox / cloud_big_partition / finalize_global: W contexts stand in for W ranks; the
     concatenated slice merges must equal the single-context merge over all frames, bit for bit."""
+    if sort_form:  # the older form of the partition (sort (part, index) records, gather) stays available
+        monkeypatch.setenv("O3DR_PARTITION_SORT", "1")
     import online_3d_reconstruction_amd as o3dr
     from online_3d_reconstruction_amd import synth
     from online_3d_reconstruction_amd.dist import shard_range
