@@ -51,6 +51,7 @@ extern "C" {
 #define O3DR_ERR_CAPACITY       -4 /* caller's output buffer is too small */
 #define O3DR_ERR_NOT_CONFIGURED -5 /* o3dr_set_camera not called yet */
 #define O3DR_ERR_ALLOC          -6
+#define O3DR_ERR_INTERNAL       -7 /* a device-side consistency guard tripped (O3DR_STATUS_INTERNAL): results are invalid */
 
 /* `mem` values */
 #define O3DR_MEM_HOST   0
@@ -60,6 +61,10 @@ extern "C" {
 #define O3DR_STATUS_VOXEL_OVERFLOW 1u /* PCL VoxelGrid "Leaf size is too small ... Integer indices
                                          would overflow": output = input, unfiltered [PCL 1.8
                                          filters/impl/voxel_grid.hpp applyFilter] */
+
+#define O3DR_STATUS_INTERNAL 0x80000000u /* a gather guard found a record or point id outside its cloud (library
+                                            bug, never expected); calls that read the status return
+                                            O3DR_ERR_INTERNAL and an empty output */
 
 typedef struct o3dr_point {
     float    x, y, z;
@@ -76,8 +81,8 @@ typedef struct o3dr_params {
     uint32_t min_points_per_voxel; /* pose.h:108 = 1; only the combined merge uses it (pose_functions.cpp:1693) */
     int32_t  dont_downsample;      /* --dont_downsample, pose.cpp:609 */
     int32_t  sor_enable;           /* statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686:
-                                      mean_k 50, 1 sigma, active iff !combined && jump_pixels > 0).  0 = off (the
-                                      measured GPU configs); 1 = on, as in the reference */
+                                      mean_k 50, 1 sigma, active iff !combined && jump_pixels > 0).  1 = on, as in the
+                                      reference (the default); 0 = off (the measured GPU configs) */
     int32_t  blur_kernel;          /* pose.h:98 blur_kernel = 1; > 1: the disparity image goes through
                                       cv::bilateralFilter(d = blur_kernel, sigmaColor = 2*blur_kernel,
                                       sigmaSpace = blur_kernel/2 (integer division)) first, pose_functions.cpp:1040-1047 */

@@ -10,9 +10,10 @@ _LIB = os.path.join(_HERE, "lib", "libo3dr.so")
 POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
 
 OK = 0
-ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_NOT_CONFIGURED, ERR_ALLOC = -1, -2, -3, -4, -5, -6
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_NOT_CONFIGURED, ERR_ALLOC, ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_VOXEL_OVERFLOW = 1
+STATUS_INTERNAL = 0x80000000
 K_COUNT, K_REPROJECT, K_KEYGEN, K_SORT_HIST, K_SORT_SCATTER, K_SEGMENT, K_CENTROID, K_OTHER, K_CENTROID_RUNS = range(9)
 KERNEL_NAMES = ["reproject_count", "reproject_emit", "voxel_keys", "radix_hist", "radix_scatter", "run_segments",
                 "centroid", "other", "centroid_runs", "window_group"]

@@ -25,7 +25,7 @@ class Params:
     jump_pixels: int = 10
     min_points_per_voxel: int = 1
     dont_downsample: bool = False
-    sor_enable: bool = False
+    sor_enable: bool = True      # the reference always runs it when !combined && jump_pixels > 0 (pose_functions.cpp:1673)
     blur_kernel: int = 1
     disparity_f64: bool = False  # --use_segment_labels: disparity images are float64
 

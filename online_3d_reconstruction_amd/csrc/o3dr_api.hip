@@ -59,21 +59,13 @@ struct o3dr_ctx {
     bool has_Q = false;
     QLutEntry* q_lut = nullptr;  // device table for rectified-stereo Q (nullptr: general 4x4 product per pixel)
     bool q_lut_on = false;
-    // pixel-window path of o3dr_accumulate_frames (opt-in, O3DR_WINDOW=1: bit-exact but measured slower than the
-    // sort-based path): per-disparity table
-    float* win_tab = nullptr;       // device, 512 floats
-    float* win_tab_host = nullptr;  // pinned
-    int win_enable = 0;
-    bool win_tab_valid = false;
     // cv::bilateralFilter tables (colour weights | space weights | tile offsets) for the last (d, sigmas) used
     DevBuf bil_tab, st_blur, st_blur_in, st_hist;
     int bil_d = 0, bil_radius = 0, bil_maxk = 0;
     double bil_sc = 0, bil_ss = 0;
     bool bil_valid = false;
     int max_batch = 256;  // frames per launch group (O3DR_BATCH_FRAMES); also bounded by a workspace budget
-    int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs
-    int scatter_ballot = 0;  // O3DR_SCATTER=ballot: the ballot-matching scatter instead of the lane-counting one
-    int single_pass = 0;  // sort variant: 1 = look-back single-pass scatter, 0 = histogram/scan/scatter per pass
+    int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs; 2: always runs
 
     Workspace ws;
     size_t ws_elems = 0;   // frames*(cap+1) the per-point arrays were allocated for
@@ -176,10 +168,6 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
         size_t o_part = off;  off += align256(((TS * kMaxRadix + TG + TE + E) / 4096 + 8 * (size_t)F + 16) * 4);
-        size_t o_phist = off; off += align256((size_t)2048 * kMaxPasses * kMaxRadix * 4);  // partial digit histograms
-        size_t o_dst = off;   off += align256((size_t)F * kMaxPasses * kMaxRadix * 4);
-        size_t o_tick = off;  off += align256((size_t)F * kMaxPasses * 4);
-        size_t o_lb = off;    const size_t lb_bytes = align256(TS * kMaxRadix * 8); off += lb_bytes;
         size_t o_mm = off;    off += align256(MM * 4);
         size_t o_nv = off;    off += align256((size_t)F * 4);
         size_t o_nk = off;    off += align256((size_t)F * 4);
@@ -189,8 +177,6 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_geom = off;  off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_geomr = off; off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_nr = off;    off += align256((size_t)F * 4);
-        size_t o_geomg = off; off += align256((size_t)F * sizeof(VoxelGeom));
-        size_t o_winc = off;  off += align256((size_t)F * 2 * sizeof(float));
         size_t o_omm = off;   off += align256((E / 64 + 8 * (size_t)F + 64) * 6 * sizeof(float));
         size_t o_ommp = off;  off += align256((size_t)kBoxFoldBlocks * 6 * sizeof(float));
         CHK(dev_ensure(c, c->ws_block, off));
@@ -206,24 +192,12 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.run_len = (uint32_t*)(base + o_rl);
         w.geom_runs = (VoxelGeom*)(base + o_geomr);
         w.n_runs = (uint32_t*)(base + o_nr);
-        w.geom_gen = (VoxelGeom*)(base + o_geomg);
-        w.win_c = (float*)(base + o_winc);
         w.out_mm = (float*)(base + o_omm);
         w.out_mm_partial = (float*)(base + o_ommp);
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
         w.scan_partial = (uint32_t*)(base + o_part);
-        w.partial_hist = (uint32_t*)(base + o_phist);
-        w.digit_start = (uint32_t*)(base + o_dst);
-        w.tickets = (uint32_t*)(base + o_tick);
-        w.lb_state = (uint64_t*)(base + o_lb);
-        w.lb_bytes = lb_bytes;
-        w.epoch = 0;  // fresh (or moved) look-back words: cleared once, epochs restart
-        HIPCHK(hipMemsetAsync(w.lb_state, 0, lb_bytes, c->stream));
-        w.error_flag = (uint32_t*)(c->misc_dev + 2048);
-        w.single_pass = c->single_pass;
-        w.scatter_ballot = c->scatter_ballot;
         w.mm = (float*)(base + o_mm);
         w.n_valid = (uint32_t*)(base + o_nv);
         w.n_kp = (uint32_t*)(base + o_nk);
@@ -300,7 +274,7 @@ extern "C" void o3dr_default_params(o3dr_params* p)
     p->jump_pixels = 10;            // pose.h:96
     p->min_points_per_voxel = 1;    // pose.h:108
     p->dont_downsample = 0;
-    p->sor_enable = 0;
+    p->sor_enable = 1;              // pose_functions.cpp:1673-1686: always on in the reference's per-frame path
     p->blur_kernel = 1;             // pose.h:98
     p->disparity_f64 = 0;           // use_segment_labels off
 }
@@ -336,8 +310,6 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
         hipHostMalloc((void**)&c->misc_host, 4096, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->misc_host_lut, 256 * sizeof(QLutEntry), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->q_lut, 256 * sizeof(QLutEntry)) != hipSuccess ||
-        hipMalloc((void**)&c->win_tab, 512 * sizeof(float)) != hipSuccess ||
-        hipHostMalloc((void**)&c->win_tab_host, 512 * sizeof(float), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->stats_host, sizeof(SortStats), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(O3DR_ERR_ALLOC, "counter allocation failed");
@@ -346,20 +318,13 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     (void)hipMemsetAsync(c->cc_tmp, 0, sizeof(CloudCounters), c->stream);
     (void)hipMemsetAsync(c->stats_dev, 0, sizeof(SortStats), c->stream);
     (void)hipMemsetAsync(c->misc_dev, 0, 4096, c->stream);
-    const char* sort_env = getenv("O3DR_SORT");
-    // "lookback": single-pass chained-scan variant (correct, but measured slower than the
-    // histogram/scan/scatter form on this workload: DESIGN.md section 4); default is the classic form
-    c->single_pass = (sort_env && strcmp(sort_env, "lookback") == 0) ? 1 : 0;
+    // the only environment switches, all read here, once per context (tests drive them)
     const char* hb_env = getenv("O3DR_HOST_BATCH_FRAMES");
     if (hb_env && atoi(hb_env) > 0) c->host_batch = atoi(hb_env);
     const char* ru_env = getenv("O3DR_RUNS");
     if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;       // whole-cloud grids always sort points
     else if (ru_env && atoi(ru_env) == 2) c->use_runs = 2;  // ... always sort runs (default: decided per cloud on the device)
     if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
-    const char* wi_env = getenv("O3DR_WINDOW");
-    c->win_enable = (wi_env && atoi(wi_env) == 1) ? 1 : 0;
-    const char* sc_env = getenv("O3DR_SCATTER");
-    c->scatter_ballot = (sc_env && strcmp(sc_env, "ballot") == 0) ? 1 : 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
     if (env && atoi(env) > 0) c->max_batch = atoi(env) > 512 ? 512 : atoi(env);
     (void)cloud_box_clear(c);
@@ -398,8 +363,6 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->misc_host) (void)hipHostFree(c->misc_host);
     if (c->misc_host_lut) (void)hipHostFree(c->misc_host_lut);
     if (c->q_lut) (void)hipFree(c->q_lut);
-    if (c->win_tab) (void)hipFree(c->win_tab);
-    if (c->win_tab_host) (void)hipHostFree(c->win_tab_host);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
     for (int i = 0; i < 2; ++i) {
         dev_release(c->st2_disp[i]);
@@ -459,7 +422,7 @@ extern "C" int o3dr_set_camera(o3dr_ctx* c, const double Q[16])
         }
         HIPCHK(hipMemcpyAsync(c->q_lut, h, 256 * sizeof(QLutEntry), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        c->q_lut_on = getenv("O3DR_NO_QLUT") == nullptr;
+        c->q_lut_on = true;
     }
     return O3DR_OK;
 }
@@ -552,64 +515,6 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
     a.lut = (c->q_lut_on && !a.disp_f64) ? c->q_lut : nullptr;
 }
 
-// Pixel-window voxel grouping (o3dr_kernels.hip): decide whether a fused A6 batch may use it and build the
-// per-disparity table.  With a rectified-stereo Q:
-//   * depth is a function of the disparity byte alone; if all valid levels are more than kWinCMax * leaf apart
-//     (an upper bound of how far two points of one voxel can be apart along any camera axis), two pixels of one
-//     voxel carry the same disparity;
-//   * at disparity d one candidate step moves X by jump * |Q0 / w(d)| and Y by jump * |Q5 / w(d)|, so pixels of one
-//     voxel are at most floor(c * leaf / step) candidates apart along each image axis.  The factor c <= kWinCMax
-//     comes from the frame's pose (k_window_plan); the table holds leaf / step.
-// Frames whose pose is not rigid or too far out for the rounding budget, and frames under PCL's overflow guard,
-// take the sort-based path inside the same launches.
-static bool window_plan(o3dr_ctx* c, const GridShape& g, int rows, int cols, float leaf, WindowPlan* w)
-{
-    if (!c->win_enable || !c->q_lut_on || c->single_pass || c->params.dont_downsample || c->params.jump_pixels < 1 ||
-        c->params.disparity_f64)  // (the depth-level argument needs integer disparities)
-        return false;
-    const QLutEntry* lut = (const QLutEntry*)c->misc_host_lut;
-    const double* Q = c->Q;
-    if (Q[0] == 0.0 || Q[5] == 0.0 || !(leaf > 0.f)) return false;
-    const double reach = (double)kWinCMax * (double)leaf;
-    const double xm = fmax(fabs(Q[0] * (double)g.cs + Q[3]), fabs(Q[0] * (double)cols + Q[3]));
-    const double ym = fmax(fabs(Q[5] * 0.0 + Q[7]), fabs(Q[5] * (double)rows + Q[7]));
-    double rho = 0.0, zs[256];
-    int nz = 0;
-    float tab[512];
-    for (int d = 0; d < 256; ++d) {
-        tab[d] = tab[256 + d] = 0.f;
-        if (!((double)d > c->params.min_disparity)) continue;
-        const double al = fabs(lut[d].alpha), z = (double)lut[d].z;
-        if (!(al > 0.0) || !std::isfinite(al) || !std::isfinite(z)) return false;
-        zs[nz++] = z;
-        const double bu = (double)leaf / (fabs(Q[0]) * al * c->params.jump_pixels);
-        const double bv = (double)leaf / (fabs(Q[5]) * al * c->params.jump_pixels);
-        if ((double)kWinCMax * bu * 1.00001 >= (double)kWinHalo + 1.0 || (double)kWinCMax * bv * 1.00001 >= (double)kWinHalo + 1.0)
-            return false;  // a radius could exceed the halo the tile kernel supports
-        tab[d] = nextafterf((float)bu, INFINITY);
-        tab[256 + d] = nextafterf((float)bv, INFINITY);
-        const double r = sqrt((xm * al) * (xm * al) + (ym * al) * (ym * al) + z * z);
-        if (r > rho) rho = r;
-    }
-    if (nz == 0) return false;
-    std::sort(zs, zs + nz);
-    for (int i = 1; i < nz; ++i)
-        if (!(zs[i] - zs[i - 1] > reach)) return false;  // two depth levels could meet in one voxel
-    if (!c->win_tab_valid || memcmp(tab, c->win_tab_host, sizeof tab) != 0) {
-        // earlier batches may still be reading the device table (and an upload the pinned one): drain first
-        if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
-        memcpy(c->win_tab_host, tab, sizeof tab);
-        if (hipMemcpyAsync(c->win_tab, c->win_tab_host, sizeof tab, hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
-        c->win_tab_valid = true;
-    }
-    w->wbase = c->win_tab;
-    w->rho_max = (float)rho;
-    // rounding may stretch the distance of two points by 2 err per axis; k_window_plan's factor allows 0.025 leaf each
-    w->err_budget = (float)(0.025 * (double)leaf);
-    w->n_kp = c->ws.n_kp;
-    return true;
-}
-
 // stage a host buffer into HBM (or pass a device pointer through)
 static int stage_in(o3dr_ctx* c, DevBuf& b, const void* src, size_t bytes, int mem, const void** dev)
 {
@@ -627,10 +532,10 @@ static int stage_in(o3dr_ctx* c, DevBuf& b, const void* src, size_t bytes, int m
 static int read_counters(o3dr_ctx* c, const CloudCounters* dev, CloudCounters* host)
 {
     HIPCHK(hipMemcpyAsync(c->cc_host, dev, sizeof(CloudCounters), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->n_host + 2, c->misc_dev + 2048, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *host = *c->cc_host;
-    if (c->n_host[2] != 0) return fail(O3DR_ERR_HIP, "radix look-back wait timed out (internal error); results are invalid");
+    if (host->status & O3DR_STATUS_INTERNAL)
+        return fail(O3DR_ERR_INTERNAL, "a device-side gather guard tripped (record or point id outside its cloud); results are invalid");
     return O3DR_OK;
 }
 
@@ -1296,9 +1201,6 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }
     CHK(ws_ensure(c, B, cap, true));
-    WindowPlan wplan;
-    const bool use_window = !use_kp && window_plan(c, g, rows, cols, leaf[0], &wplan);
-
     const bool streaming = mem == O3DR_MEM_HOST;
     if (streaming) {
         // Host buffers: frames cross PCIe once.  Upload batch k+1 on a second stream while batch k
@@ -1346,17 +1248,9 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
         if (use_kp)
             launch_keypoint_pass(&c->prof, c->stream, a, kp_d, 0, c->ws.pts, c->ws.n_kp, c->ws.mm, kpoff_d + f0, nb);
-        if (use_window) {
-            // bounding boxes only; the window kernel inside launch_voxel_grid redoes the reprojection in LDS
-            wplan.a = a;
-            launch_frame_bbox(&c->prof, c->stream, a, nb, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
-                              c->ws.scan_partial);
-        } else
-            launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
-                             c->ws.scan_partial);
+        launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
+                         c->ws.scan_partial);
         VoxelArgs v;
-        v.window = use_window ? &wplan : nullptr;
-        if (use_window) c->cloud_box_valid = false;  // the window path's gather does not track it
         v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
         v.in = c->ws.pts;
         v.in_fstride = cap;
@@ -1535,7 +1429,8 @@ extern "C" int o3dr_cloud_big_partition(o3dr_ctx* c, const float gmin[3], const 
 {
     if (status) *status = 0;
     CTX_ENTER(c);
-    if (!gmin || !gmax || !counts || n_parts < 1 || n_parts > 256) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    if (!gmin || !gmax || !counts || n_parts < 1 || n_parts > kMaxRadix)
+        return fail(O3DR_ERR_INVALID_ARG, "bad arguments (1 <= n_parts <= 128)");
     for (int p = 0; p < n_parts; ++p) counts[p] = 0;
     CloudCounters cc;
     CHK(read_counters(c, c->cc_big, &cc));
@@ -1674,7 +1569,7 @@ extern "C" int o3dr_profile_stats(o3dr_ctx* c, int64_t out[8])
     out[0] = (int64_t)c->stats_host->sort_record_passes;
     out[1] = (int64_t)c->stats_host->voxel_points_in;
     out[2] = (int64_t)c->stats_host->voxel_points_out;
-    out[3] = (int64_t)c->stats_host->window_frames;
+    out[3] = 0;
     out[4] = (int64_t)c->stats_host->sort_records;
     out[5] = out[6] = out[7] = 0;
     return O3DR_OK;

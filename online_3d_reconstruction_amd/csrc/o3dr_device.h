@@ -41,8 +41,7 @@ struct VoxelGeom {
     uint32_t n;           // points in this frame
     uint32_t passes;      // radix passes this frame's index needs (0 when overflow)
     uint32_t bpp;         // bits per pass
-    uint32_t buf0;        // bit 0: buffer the first pass reads (sorted records end in buffer (passes + buf0) & 1);
-                          // bit 1: window frame (records are voxels formed in image tiles)
+    uint32_t buf0;        // buffer the first pass reads (sorted records end in buffer (passes + buf0) & 1)
     uint32_t val_bits;    // run-compressed sorts: payload = first point | (points - 1) << val_bits; 0: payload = record id
 };
 
@@ -104,23 +103,11 @@ struct Workspace {
     double* sor_partial = nullptr;      // 256*2
     o3dr_point* sor_pts = nullptr;      // cap      inliers
     uint32_t* sor_n = nullptr;          // 1        inlier count
-    // single-pass (look-back) sort
-    int single_pass = 0;               // 1: k_voxel_keys_hist + k_radix_scatter<true>; 0: hist/scan/scatter per pass
-    int scatter_ballot = 0;            // 1: ballot-matching scatter (k_radix_scatter); 0: lane-counting (k_radix_scatter_lane)
-    uint32_t* partial_hist = nullptr;  // 2048*kMaxPasses*kMaxRadix  per-workgroup digit histograms of k_voxel_keys_hist
-    uint32_t* digit_start = nullptr;   // frames*kMaxPasses*kMaxRadix  exclusive digit starts per pass
-    uint64_t* lb_state = nullptr;      // (sort tiles)*kMaxRadix  chained-scan words, zeroed once at allocation
-    size_t lb_bytes = 0;
-    uint32_t* tickets = nullptr;       // frames*kMaxPasses
-    uint32_t* error_flag = nullptr;    // set when a look-back spin gives up
-    uint32_t epoch = 0;                // epoch of the last look-back launch (22 bits used)
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
     uint32_t* run_start = nullptr; // frames*(cap+1)  first point of every run (run-compressed path)
     uint32_t* run_len = nullptr;   // frames*(cap+1)  run lengths in sorted order -> exclusive prefix (min_points > 1)
     uint32_t* n_runs = nullptr;    // frames
     VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of runs, records starting in buffer 1
-    VoxelGeom* geom_gen = nullptr;   // frames: geom with n = 0 for frames taken by the pixel-window path
-    float* win_c = nullptr;          // frames*2: per-frame factors on the window table (k_window_plan)
     float* out_mm = nullptr;         // frames*ceil(cap/256)*4*6: bounding boxes of what k_centroid's waves appended
     float* out_mm_partial = nullptr; // kBoxFoldBlocks*6
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
@@ -139,8 +126,8 @@ struct SortStats {
     uint64_t sort_record_passes;  // sum over voxel jobs of points * radix passes
     uint64_t voxel_points_in;     // points entering voxel grids (not counting overflow/passthrough)
     uint64_t voxel_points_out;    // points leaving them
-    uint64_t window_frames;       // frames of fused A6 batches that took the pixel-window path
-    uint64_t sort_records;        // records entering the sorts (points, runs, or voxel records of window frames)
+    uint64_t reserved;
+    uint64_t sort_records;        // records entering the sorts (points, or runs of points)
     uint64_t pad[3];
 };
 
@@ -183,22 +170,8 @@ struct VoxelArgs {
     SortStats* stats; // optional device statistics
     int use_runs;     // sort runs of consecutive equal indices instead of points (whole-cloud calls)
     float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
-    const struct WindowPlan* window = nullptr;  // non-null: fused A6 batch whose frames may take the pixel-window path
-};
-// Pixel-window voxel grouping of the fused per-frame path (o3dr_kernels.hip, "Pixel-window voxel grouping").
-// The caller has run launch_frame_bbox instead of launch_reproject; v.in is the (not yet written) point buffer.
-struct WindowPlan {
-    ReprojectArgs a;
-    const float* wbase;   // device, 512 floats: leaf / (candidate spacing in metres at disparity d) along x [d], y [256 + d]
-    float rho_max;        // largest camera-frame range of a valid pixel (metres)
-    float err_budget;     // allowed fp32 rounding error of a world coordinate (metres)
-    const uint32_t* n_kp; // zeros
 };
 constexpr int kBoxFoldBlocks = 1024;  // workgroups (and partial boxes) of the running-bounding-box fold
-constexpr int kWinHalo = 8;        // largest window radius (candidates) the tile kernel supports
-constexpr float kWinCMax = 1.9f;   // largest per-frame factor on the table (>= 1.06 * sqrt(3) * 1.005 + 0.05)
-void launch_frame_bbox(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, uint32_t* tile_cnt,
-                       const uint32_t* n_kp, uint32_t* n_valid, float* mm, uint32_t* scan_partial);
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);
 // cv::bilateralFilter on u8 images; tab = color_weight[256] | space_weight[maxk] | tile offsets [maxk] (device)

@@ -2,7 +2,7 @@
 //
 //   K1  k_reproject_count / k_reproject_emit   A1+A2: (u,v,disparity) -> Q -> SE(3) -> ordered cloud
 //   K2  k_voxel_geom / k_voxel_keys            A4 steps 1-5: PCL VoxelGrid geometry and linear index
-//       k_radix_hist / k_radix_scatter         A4 step 6: stable LSD radix sort of (index, point id)
+//       k_radix_hist / k_radix_scatter_lane    A4 step 6: stable LSD radix sort of (index, point id)
 //       k_run_heads / k_run_starts / k_centroid  A4 steps 7-8: runs -> ordered fp32 centroid
 //
 // Everything here is HBM-bound integer/byte/fp32 work: no MFMA.  The whole translation unit is
@@ -18,9 +18,8 @@
 //   reproject    K1: count / emit / keypoint pass / in-place transform
 //   bookkeeping  slot initialisation, exclusive scans, bounding box of a cloud
 //   prepass      bilateral filter and variance gate on the disparity image
-//   window       opt-in pixel-window voxel grouping
 //   voxel_index  PCL VoxelGrid geometry, linear indices (+ fused first histogram / run-head counts)
-//   radix_sort   digit histograms and the stable scatters (lane-counting, ballot, look-back)
+//   radix_sort   digit histograms and the stable lane-counting scatter
 //   voxel_runs   run heads/starts, min_points filter, centroid kernels, run-compressed variants, running bbox
 //   multigpu     bounding-box fold, index-slice partition
 //   sor          statistical outlier removal
@@ -34,7 +33,6 @@ namespace o3dr {
 #include "kernels/reproject.inc"
 #include "kernels/bookkeeping.inc"
 #include "kernels/prepass.inc"
-#include "kernels/window.inc"
 #include "kernels/voxel_index.inc"
 #include "kernels/radix_sort.inc"
 #include "kernels/voxel_runs.inc"
@@ -105,23 +103,9 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
         if (a.disp_f64)
-            k_reproject_emit<true><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr);
+            k_reproject_emit<true><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
         else
-            k_reproject_emit<false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr);
-    }
-}
-
-void launch_frame_bbox(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, uint32_t* tile_cnt,
-                       const uint32_t* n_kp, uint32_t* n_valid, float* mm, uint32_t* scan_partial)
-{
-    const dim3 grid(a.n_tiles, frames);
-    {
-        ProfScope ps(pf, O3DR_K_COUNT, s);
-        k_frame_bbox<<<grid, kEmitThreads, 0, s>>>(a, tile_cnt, mm);
-    }
-    {
-        ProfScope ps(pf, O3DR_K_OTHER, s);
-        launch_scan(s, tile_cnt, a.n_tiles, a.n_tiles, frames, n_valid, n_kp, scan_partial);
+            k_reproject_emit<false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
     }
 }
 
@@ -160,123 +144,59 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                                        v.z_offset, ws.geom);
     }
     uint32_t* n_keep = nullptr;
-    // run compression: whole-cloud calls only, and not together with the look-back variant
-    const bool use_runs = v.use_runs && !ws.single_pass && !v.passthrough;
-    const WindowPlan* w = (v.window && !use_runs && !ws.single_pass && !v.passthrough && cap > 0) ? v.window : nullptr;
-    // what the sort and the run/cell kernels count (runs / voxel records of window frames / points)
-    const VoxelGeom* sort_geom = (use_runs || w) ? ws.geom_runs : ws.geom;
-    // what the per-point kernels of the sort-based path see: frames on the window path have n = 0 there
-    const VoxelGeom* gen_geom = w ? ws.geom_gen : ws.geom;
-    const VoxelGeom* seg_geom = w ? ws.geom_gen : sort_geom;
-    // plain point sort (per-frame grids of a batch): the index kernel also counts the first pass's digits
-    const bool fuse_hist0 = !use_runs && !w && !ws.single_pass && !getenv("O3DR_NO_FUSE_HIST0");
-    if (w) {
-        {
-            ProfScope ps(pf, O3DR_K_OTHER, s);
-            k_window_plan<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, w->a.poses, F, w->rho_max, w->err_budget, ws.geom_gen, ws.n_runs,
-                                                       ws.win_c);
-        }
-        {
-            ProfScope ps(pf, O3DR_K_REPROJECT, s);
-            k_reproject_emit<false><<<dim3(w->a.n_tiles, F), kEmitThreads, 0, s>>>(w->a, const_cast<o3dr_point*>(v.in), ws.tile_cnt,
-                                                                             w->n_kp, ws.mm, ws.geom_gen);
-        }
-        {
-            ProfScope ps(pf, O3DR_K_WINDOW, s);
-            const int tiles_x = cdiv64(w->a.Nx, kWinTX), tiles_y = cdiv64(w->a.Ny, kWinTY);
-            k_window_group<<<dim3(tiles_y, F), 256, 0, s>>>(w->a, w->wbase, ws.win_c, tiles_x, ws.geom, ws.geom_gen, cap,
-                                                                      ws.keys[1], const_cast<o3dr_point*>(v.in), ws.n_runs);
-        }
-        {
-            ProfScope ps(pf, O3DR_K_OTHER, s);
-            k_window_sort_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.geom_gen, ws.n_runs, F, ws.geom_runs);
-        }
-    }
+    // run compression: whole-cloud calls only
+    const bool use_runs = v.use_runs && !v.passthrough;
+    // what the sort and the run/cell kernels count (runs or points)
+    const VoxelGeom* sort_geom = use_runs ? ws.geom_runs : ws.geom;
     if (!v.passthrough && cap > 0) {
         const dim3 grid(n_sort_tiles, F);
-        if (ws.single_pass) {
-            // keys + all digit histograms in one read of the points; then one look-back scatter per pass
-            int nblk = 2048 / F;
-            if (nblk > 256) nblk = 256;
-            const int max_blk = cdiv64(cap, kKeyThreads * 4);
-            if (nblk > max_blk) nblk = max_blk;
-            if (nblk < 1) nblk = 1;
+        {
+            ProfScope ps(pf, O3DR_K_KEYGEN, s);
+            if (use_runs)  // indices and, in the same read, how many runs of equal indices start in every tile
+                k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
+                                                                       ws.keys[0], n_seg_tiles, ws.seg_cnt);
+            else  // ... and the histogram of the first radix pass
+                k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap, ws.keys[0],
+                                                                 n_sort_tiles, ws.hist);
+        }
+        if (use_runs) {
+            // runs of consecutive equal indices -> (run key, run id) records in buffer 1
+            const dim3 rgrid(n_seg_tiles, F);
             {
-                ProfScope ps(pf, O3DR_K_KEYGEN, s);
-                k_voxel_keys_hist<<<dim3(nblk, F), kKeyThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
-                                                                       ws.keys[0], nblk, ws.partial_hist);
+                ProfScope ps(pf, O3DR_K_OTHER, s);
+                launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_runs, nullptr, ws.scan_partial);
+            }
+            {
+                ProfScope ps(pf, O3DR_K_SEGMENT, s);
+                // runs or points?  (decided per cloud on the device; use_runs == 2 forces runs)
+                k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs, v.use_runs > 1 ? 1 : 0);
+                k_run_starts<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
+                                                  ws.run_start, 0, ws.keys[1], ws.geom_runs);  // run keys -> buffer 1
+            }
+        }
+        // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
+        const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
+        for (int pass = 0; pass < kMaxPasses; ++pass) {
+            if (!(pass == 0 && !use_runs)) {
+                ProfScope ps(pf, O3DR_K_SORT_HIST, s);
+                k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, pass, n_sort_tiles,
+                                                          ws.hist);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
-                k_digit_starts<<<F, kMaxRadix, 0, s>>>(ws.partial_hist, nblk, ws.geom, ws.digit_start, ws.tickets);
-                if (ws.epoch > 0x3ffff0u - 8u) {  // epoch field about to wrap: clear the words, restart
-                    (void)hipMemsetAsync(ws.lb_state, 0, ws.lb_bytes, s);
-                    ws.epoch = 0;
-                }
+                launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, sort_geom, pass,
+                            n_sort_tiles);
             }
-            for (int pass = 0; pass < kMaxPasses; ++pass) {
-                ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
-                k_radix_scatter<true><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                   ws.geom, pass, n_sort_tiles, nullptr, ws.digit_start,
-                                                                   ws.lb_state, ws.tickets, ++ws.epoch, ws.error_flag, nullptr);
-            }
-        } else {
             {
-                ProfScope ps(pf, O3DR_K_KEYGEN, s);
-                if (use_runs)  // indices and, in the same read, how many runs of equal indices start in every tile
-                    k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
-                                                                           ws.keys[0], n_seg_tiles, ws.seg_cnt);
-                else if (fuse_hist0)  // ... and the histogram of the first radix pass
-                    k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, gen_geom, v.z_offset, cap, ws.keys[0],
-                                                                     n_sort_tiles, ws.hist);
-                else
-                    k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), F), kPtThreads, 0, s>>>(v.in, v.in_fstride, gen_geom,
-                                                                                            v.z_offset, cap, ws.keys[0]);
-            }
-            if (use_runs) {
-                // runs of consecutive equal indices -> (run key, run id) records in buffer 1
-                const dim3 rgrid(n_seg_tiles, F);
-                {
-                    ProfScope ps(pf, O3DR_K_OTHER, s);
-                    launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_runs, nullptr, ws.scan_partial);
-                }
-                {
-                    ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                    // runs or points?  (decided per cloud on the device; O3DR_RUNS=2 forces runs)
-                    k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs, v.use_runs > 1 ? 1 : 0);
-                    k_run_starts<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
-                                                      ws.run_start, 0, ws.keys[1], ws.geom_runs);  // run keys -> buffer 1
-                }
-            }
-            // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
-            const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
-            for (int pass = 0; pass < kMaxPasses; ++pass) {
-                if (!(pass == 0 && fuse_hist0)) {
-                    ProfScope ps(pf, O3DR_K_SORT_HIST, s);
-                    k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, pass, n_sort_tiles,
-                                                              ws.hist);
-                }
-                {
-                    ProfScope ps(pf, O3DR_K_OTHER, s);
-                    launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, sort_geom, pass,
-                                n_sort_tiles);
-                }
-                {
-                    ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
-                    if (ws.scatter_ballot)
-                        k_radix_scatter<false><<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                            sort_geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
-                                                                            nullptr, 0u, nullptr, ws.run_start);
-                    else
-                        k_radix_scatter_lane<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                          sort_geom, pass, n_sort_tiles, ws.hist, ws.run_start);
-                }
+                ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
+                k_radix_scatter_lane<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                  sort_geom, pass, n_sort_tiles, ws.hist, ws.run_start);
             }
         }
         const dim3 sgrid(n_seg_tiles, F);
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, seg_geom, n_seg_tiles, ws.seg_cnt, -1);
+            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, -1);
         }
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -284,7 +204,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         }
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, seg_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
+            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
                                               ws.seg_start, -1, nullptr, nullptr);
         }
         if (v.min_points > 1) {
@@ -299,7 +219,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                     k_keep_count_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
                                                            n_seg_tiles, ws.seg_cnt);
                 }
-                k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, seg_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt);
+                k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, sort_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -310,7 +230,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 if (use_runs)
                     k_keep_write_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
                                                            n_seg_tiles, ws.seg_cnt, ws.keep_idx);
-                k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, seg_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt,
+                k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, sort_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt,
                                                   ws.keep_idx);
             }
             n_keep = ws.n_out;
@@ -326,25 +246,22 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         ProfScope ps(pf, O3DR_K_CENTROID_RUNS, s);
         k_centroid_runs<<<dim3(nbx, F), kPtThreads, 0, s>>>(
             v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, ws.run_start,
-            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.n_out, ws.out_off, v.z_offset, v.out_base);
+            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.geom, ws.n_out, ws.out_off, v.z_offset, v.out_base, v.cc);
     }
     if (cap > 0) {
         ProfScope ps(pf, O3DR_K_CENTROID, s);
-        float* out_mm = (v.cloud_box && !w) ? ws.out_mm : nullptr;
+        float* out_mm = v.cloud_box ? ws.out_mm : nullptr;
         const uint32_t* keep = (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr;
         if (use_runs)  // only for clouds k_run_geom left to the point sort: a small looping grid
             k_centroid<true><<<dim3(nbx < 4096 ? nbx : 4096, F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom_runs, ws.n_out, ws.out_off,
-                v.z_offset, v.passthrough, v.out_base, out_mm, nbx);
+                v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc);
         else
             k_centroid<false><<<dim3(nbx, F), kPtThreads, 0, s>>>(
-                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, gen_geom, ws.n_out, ws.out_off,
-                v.z_offset, v.passthrough, v.out_base, out_mm, nbx);
-        if (w)
-            k_gather_heads<<<dim3(cdiv64(cap, kPtThreads), F), kPtThreads, 0, s>>>(v.in, cap, ws.vals[0], ws.vals[1], ws.geom_runs,
-                                                                                 ws.n_out, ws.out_off, v.out_base);
+                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom, ws.n_out, ws.out_off,
+                v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc);
     }
-    if (v.cloud_box && cap > 0 && !use_runs && !w) {
+    if (v.cloud_box && cap > 0 && !use_runs) {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         const int nbx = cdiv64(cap, kPtThreads) * (kPtThreads / 64);
         k_cloud_bbox_fold<<<kBoxFoldBlocks, 256, 0, s>>>(ws.out_mm, nbx, F, ws.n_out, ws.out_mm_partial);
@@ -392,25 +309,12 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
     const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
     ProfScope ps(pf, O3DR_K_OTHER, s);
     k_voxel_geom<<<1, 256, 0, s>>>(ws.mm, ws.mm_stride, 1, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset, ws.geom);
-    if (n_parts <= kMaxRadix && !getenv("O3DR_PARTITION_SORT")) {
-        // direct form: count per (part, tile), scan, move the points (two reads and one write of the cloud)
-        k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
-        k_part_count<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist);
-        launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, 0, n_sort_tiles);
-        k_part_move<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist, out);
-        k_part_counts_scanned<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.hist, ws.geom, n_parts, n_sort_tiles, counts_dev, overflow_dev);
-        return;
-    }
-    k_voxel_keys<<<dim3(cdiv64(cap, kPtThreads * 4), 1), kPtThreads, 0, s>>>(v.in, 0, ws.geom, v.z_offset, cap, ws.keys[0]);
-    k_part_ids<<<cdiv64(cap, 256), 256, 0, s>>>(ws.keys[0], ws.geom, n_parts);
+    // count per (part, tile), scan, move the points (two reads and one write of the cloud); n_parts <= kMaxRadix
     k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
-    k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, 0, n_sort_tiles, ws.hist);
+    k_part_count<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist);
     launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, 0, n_sort_tiles);
-    k_radix_scatter<false><<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                         ws.geom, 0, n_sort_tiles, ws.hist, nullptr, nullptr, nullptr,
-                                                                         0u, nullptr, nullptr);
-    k_gather_points<<<cdiv64(cap, 256), 256, 0, s>>>(v.in, ws.vals[1], ws.geom, out);
-    k_part_counts<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.keys[1], ws.geom, n_parts, counts_dev, overflow_dev);
+    k_part_move<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist, out);
+    k_part_counts_scanned<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.hist, ws.geom, n_parts, n_sort_tiles, counts_dev, overflow_dev);
 }
 
 // Statistical outlier removal of ONE cloud (`in`, count in n_dev[0], at most cap points, bounding boxes in
@@ -430,9 +334,8 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     for (int pass = 0; pass < kMaxPasses; ++pass) {
         k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
         launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
-        k_radix_scatter<false><<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                             ws.geom, pass, n_sort_tiles, ws.hist, nullptr, nullptr,
-                                                                             nullptr, 0u, nullptr, nullptr);
+        k_radix_scatter_lane<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
+                                                                           ws.geom, pass, n_sort_tiles, ws.hist, nullptr);
     }
     k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
                                                      ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);

@@ -75,7 +75,10 @@ public:
     int cutout_ratio = 8;
     bool dont_downsample = false, downsample = false, log_stuff = false, only_MAVLink = true, dont_icp = true;
     bool reference_fanout = false;  // run A6 through createAndTransformPtCloud on 7 host threads
-    bool sor = false;               // statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686)
+    bool sor = true;                // statistical outlier removal of the per-frame path (pose_functions.cpp:1673-1686:
+                                    // always on in the reference when jump_pixels > 0); `--sor 0` switches it off
+    std::string keypointsPrefix;    // --keypoints_dir: <img_num>.txt with one "x y" pair per line (KeyPoint::pt of the
+                                    // frame's ORB features, which this build does not compute); empty = no keypoints
     std::array<double, 16> Q{};
     std::string calib_file = "cam13calib.yml";
     std::string dataFilesPrefix = "data_files/", imagePrefix = "images/", disparityPrefix = "disparities/";

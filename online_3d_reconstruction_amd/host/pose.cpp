@@ -387,6 +387,9 @@ void Pose::printUsage()
     cout << "./pose first_img last_img [--voxel_size m] [--jump_pixels n] [--min_points_per_voxel n] [--seq_len n]\n"
             "       [--dont_downsample] [--log 0|1] [--only_MAVLink] [--dont_icp] [--reference_fanout] [--sor 0|1]\n"
             "       [--data_dir d/] [--image_dir d/] [--disparity_dir d/] [--output_dir d/] [--calib_file f] [--device n]\n"
+            "       [--keypoints_dir d/]   (d/<img_num>.txt: one \"x y\" keypoint per line; used iff jump_pixels != 1)\n"
+            "--sor defaults to 1: like the reference, every per-frame cloud goes through StatisticalOutlierRemoval(50, 1.0)\n"
+            "before its voxel grid when jump_pixels > 0.\n"
             "./pose --downsample file.ply [--voxel_size m] [--min_points_per_voxel n]\n"
             "Pose estimation (ORB matching, ICP), visualisation and the mesh/segment tools are not part of this build.\n";
 }
@@ -421,6 +424,7 @@ int Pose::parseCmdArgs(int argc, char** argv)
         else if (a == "--image_dir") imagePrefix = need(i);
         else if (a == "--disparity_dir") disparityPrefix = need(i);
         else if (a == "--output_dir") outputPrefix = need(i);
+        else if (a == "--keypoints_dir") keypointsPrefix = need(i);
         else if (a == "--calib_file") calib_file = need(i);
         else if (a == "--device") device_id = atoi(need(i));
         else if (a == "--dist_nearby" || a == "--search_radius" || a == "--range_width") { need(i); }
@@ -478,6 +482,9 @@ void Pose::run_reconstruction()
     const int cycle_len = seq_len > 0 ? seq_len : (int)rawImageDataVec.size();
     int current_idx = 0, cycle = 0;
     acceptedImageDataVec.reserve(rawImageDataVec.size());
+    if (!sor && jump_pixels > 0)
+        cout << "NOTE: --sor 0: the per-frame StatisticalOutlierRemoval of the reference (pose_functions.cpp:1673-1686) is OFF;\n"
+                "      the clouds differ from the reference's for the same command line." << endl;
     cout << "\n\nProgram Start!" << endl;
     while (current_idx <= last_idx) {
         cout << "\nCycle " << cycle << endl;
@@ -494,6 +501,15 @@ void Pose::run_reconstruction()
             d.raw_img_data_ptr = &r;
             d.t_mat_MAVLink = generateTmat(current_idx);
             d.t_mat_FeatureMatched = d.t_mat_MAVLink;  // --only_MAVLink, pose.cpp:238
+            if (!keypointsPrefix.empty()) {
+                // the list the reference's ORB stage would leave in features.keypoints (pose_functions.cpp:1057-1061)
+                ifstream kf(keypointsPrefix + to_string(r.img_num) + ".txt");
+                float kx, ky;
+                while (kf >> kx >> ky) {
+                    d.keypoints_xy.push_back(kx);
+                    d.keypoints_xy.push_back(ky);
+                }
+            }
             acceptedImageDataVec.push_back(d);
             cout << "\tAccepted!" << endl;
             current_idx++;
@@ -522,16 +538,20 @@ void Pose::run_reconstruction()
             const RawImageData& r0 = *acceptedImageDataVec[first_accepted].raw_img_data_ptr;
             const size_t dsz = r0.disparity_image.data.size(), csz = r0.rgb_image.data.size();
             vector<uint8_t> disp(dsz * n_acc), bgr(csz * n_acc);
-            vector<float> poses(16 * n_acc);
+            vector<float> poses(16 * n_acc), kp_xy;
+            vector<int64_t> kp_off(n_acc + 1, 0);
             for (size_t k = 0; k < n_acc; ++k) {
                 const ImageData& im = acceptedImageDataVec[first_accepted + k];
                 memcpy(&disp[k * dsz], im.raw_img_data_ptr->disparity_image.data.data(), dsz);
                 memcpy(&bgr[k * csz], im.raw_img_data_ptr->rgb_image.data.data(), csz);
                 memcpy(&poses[16 * k], im.t_mat_FeatureMatched.data(), 64);
+                kp_xy.insert(kp_xy.end(), im.keypoints_xy.begin(), im.keypoints_xy.end());
+                kp_off[k + 1] = (int64_t)(kp_xy.size() / 2);
                 cout << " " << im.raw_img_data_ptr->img_num << flush;
             }
-            chk(o3dr_accumulate_frames(c, disp.data(), (int64_t)dsz, cols, bgr.data(), (int64_t)csz, 3 * (int64_t)cols, rows, cols,
-                                       poses.data(), (int32_t)n_acc, O3DR_MEM_HOST),
+            chk(o3dr_accumulate_frames_kp(c, disp.data(), (int64_t)dsz, cols, bgr.data(), (int64_t)csz, 3 * (int64_t)cols, rows,
+                                          cols, poses.data(), (int32_t)n_acc, kp_xy.empty() ? nullptr : kp_xy.data(),
+                                          kp_xy.empty() ? nullptr : kp_off.data(), O3DR_MEM_HOST),
                 "accumulate_frames");
         }
         chk(o3dr_ctx_synchronize(c), "synchronize");

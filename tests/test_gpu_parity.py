@@ -18,7 +18,10 @@ def _pose(i=3):
 
 
 def _params(**kw):
+    """Params for stage-wise parity: statistical outlier removal OFF unless a test asks for it (SURVEY 8a row A3b;
+    the library's own default is ON, like the reference's per-frame path)."""
     import online_3d_reconstruction_amd as o3dr
+    kw.setdefault("sor_enable", False)
     return o3dr.Params(**kw)
 
 
@@ -300,12 +303,10 @@ def test_full_size_properties(ctx):
 
 
 # ---- multi-GPU merge pieces on one GPU: virtual ranks, exchange done by hand ---------------------------
-@pytest.mark.parametrize("world,sort_form", [(2, False), (5, False), (3, True), (8, False)])
-def test_partitioned_merge_virtual_ranks(Q, orc, world, sort_form, monkeypatch):
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+def test_partitioned_merge_virtual_ranks(Q, orc, world):
     """cloud_big_bbox / cloud_big_partition / finalize_global: W contexts stand in for W ranks; the
     concatenated slice merges must equal the single-context merge over all frames, bit for bit."""
-    if sort_form:  # the older form of the partition (sort (part, index) records, gather) stays available
-        monkeypatch.setenv("O3DR_PARTITION_SORT", "1")
     import online_3d_reconstruction_amd as o3dr
     from online_3d_reconstruction_amd import synth
     from online_3d_reconstruction_amd.dist import shard_range
@@ -313,7 +314,7 @@ def test_partitioned_merge_virtual_ranks(Q, orc, world, sort_form, monkeypatch):
     F = 11
     disp, bgr = synth.make_frames(300, F, invalid_frac=0.01)
     poses = synth.make_poses(300, F)
-    prm = o3dr.Params(jump_pixels=3, voxel_size=0.05)
+    prm = _params(jump_pixels=3, voxel_size=0.05)
     with o3dr.Context(0, Q=Qs, params=prm) as one:
         one.accumulateFrames(disp, bgr, poses)
         ref = one.finalize()
@@ -454,7 +455,7 @@ def test_zero_copy_exchange_single_rank_rccl(orc):
         Qs = synth.camera_Q()
         disp, bgr = synth.make_frames(7, 4)
         poses = synth.make_poses(7, 4)
-        with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=2, voxel_size=0.05), stream=torch.cuda.current_stream()) as c:
+        with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=2, voxel_size=0.05), stream=torch.cuda.current_stream()) as c:
             c.accumulateFrames(disp, bgr, poses)
             ref = c.finalize()
             view = c.cloudBigView()
@@ -477,7 +478,7 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
     F = 9
     disp, bgr = synth.make_frames(60, F, invalid_frac=0.01)
     poses = synth.make_poses(60, F)
-    with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=3, voxel_size=0.05)) as c:
+    with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=3, voxel_size=0.05)) as c:
         c.accumulateFrames(disp, bgr, poses)
         big = c.cloudBigRead()
         small = c.finalize()
@@ -486,11 +487,10 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
     assert_points_equal(small, rsmall, "cloud_small (streamed host input)")
 
 
-@pytest.mark.parametrize("env", [{"O3DR_SCATTER": "ballot"}, {"O3DR_SORT": "lookback"}, {"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"},
-                                 {"O3DR_NO_QLUT": "1"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_WINDOW": "1"}, {"O3DR_NO_CLOUD_BOX": "1"}, {"O3DR_NO_FUSE_HIST0": "1"}])
+@pytest.mark.parametrize("env", [{"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_NO_CLOUD_BOX": "1"}])
 def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
-    """the A/B variants kept behind environment switches (ballot-matching scatter, look-back single-pass
-    sort, per-point instead of per-run merge, general Q product, small launch groups) give the same bits"""
+    """the switches a context reads at creation (per-point instead of per-run merge and the reverse, small launch
+    groups, bounding box by a pass over the cloud) give the same bits"""
     import online_3d_reconstruction_amd as o3dr
     from online_3d_reconstruction_amd import synth
     for k, v in env.items():
@@ -499,7 +499,7 @@ def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     F = 5
     disp, bgr = synth.make_frames(11, F, invalid_frac=0.02)
     poses = synth.make_poses(11, F)
-    with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=2, voxel_size=0.05, min_points_per_voxel=2)) as c:
+    with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=2, voxel_size=0.05, min_points_per_voxel=2)) as c:
         c.accumulateFrames(disp, bgr, poses)
         big = c.cloudBigRead()
         small = c.finalize()
@@ -511,62 +511,75 @@ def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     assert_points_equal(vg, orc.voxel_grid(pts, (0.02, 0.03, 0.04), 0)[0], f"voxel grid {env}")
 
 
-def test_A7_window_path_mixed_batch(orc, monkeypatch):
-    """pixel-window voxel grouping (opt-in, O3DR_WINDOW=1): a batch whose frames take it (rigid pose) next to frames that must not
-    (scaled or sheared pose, translation too far for the fp32 margin, overflow guard) and an empty frame;
-    disparities over the whole valid range so every window radius is exercised"""
-    import online_3d_reconstruction_amd as o3dr
+# ---- empty frames inside a batch (round-1 abort: an all-invalid frame's histogram spilled into its neighbour's) ----
+@pytest.mark.parametrize("jump", [1, 15, 0])
+@pytest.mark.parametrize("empty", [(0,), (2,), (4,), (1, 2), (0, 1, 2, 3, 4)])
+def test_A7_batch_with_all_invalid_frames(ctx, orc, jump, empty):
+    """The reference accepts an all-invalid disparity image (variance 0 <= 5, pose.cpp:190) and its frame simply adds
+    no points (pose_functions.cpp:1107).  Empty frames first / in the middle / last / adjacent / all, at jump_pixels
+    1, 15 and 0 (keypoints only): cloud_big and the merge equal the oracle's, bit for bit."""
     from online_3d_reconstruction_amd import synth
-    monkeypatch.setenv("O3DR_WINDOW", "1")
     Qs = synth.camera_Q()
-    F = 7
-    disp, bgr = synth.make_frames(300, F, invalid_frac=0.03)
-    rng = np.random.default_rng(5)
-    # frame 1: slanted plane through every disparity level 65..255, noisy; frame 2: blocks of constant disparity
-    yy, xx = np.mgrid[0:720, 0:1280]
-    disp[1] = np.clip(60 + (xx * 200) // 1280 + rng.integers(-2, 3, (720, 1280)), 0, 255).astype(np.uint8)
-    disp[2] = (66 + 27 * ((xx // 97 + yy // 61) % 8)).astype(np.uint8)
-    disp[3][:] = 255
-    disp[5][:] = 0  # nothing valid
-    poses = synth.make_poses(300, F)
-    poses[4, :3, :3] *= 1.5                 # not rigid
-    poses[6, :3, 3] += np.float32(9000.0)   # rounding of world coordinates no longer negligible
-    with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=1, voxel_size=0.05)) as c:
-        c.profileReset()
-        c.accumulateFrames(disp, bgr, poses)
-        big = c.cloudBigRead()
-        n, st = c.cloudBigSize()
-        stats = c.profileStats4()
-    rbig = np.concatenate([orc.create_and_transform_pt_cloud(disp[i], bgr[i], Qs, poses[i], 0.05, jump_pixels=1)[0]
-                           for i in range(F)])
-    assert stats[3] == 4, stats  # frames 0-3 on the window path; 4 and 6 on the sort path; 5 empty
+    ctx.set_camera(Qs)
+    F = 5
+    disp, bgr = synth.make_frames(200, F, invalid_frac=0.02)
+    disp = disp.copy()
+    for f in empty:
+        disp[f][:] = 64 if f % 2 else 0  # at the threshold (strict >) or plain zero
+    poses = synth.make_poses(200, F)
+    rng = np.random.default_rng(3 + jump)
+    kps = [np.column_stack([rng.uniform(150, 1270, n), rng.uniform(10, 710, n)]).astype(np.float32) for n in (300, 0, 900, 40, 0)]
+    ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05))
+    ctx.cloudBigReset()
+    ctx.accumulateFrames(disp, bgr, poses, kps if jump != 1 else None)
+    n, st = ctx.cloudBigSize()
+    big = ctx.cloudBigRead()
+    small = ctx.finalize()
+    clouds = [orc.create_and_transform_pt_cloud(disp[i], bgr[i], Qs, poses[i], 0.05, jump_pixels=jump,
+                                                kp_xy=kps[i] if jump != 1 else None)[0] for i in range(F)]
+    for f in empty:
+        assert len(clouds[f]) == 0
+    rbig = np.concatenate(clouds)
     assert st == 0 and n == len(rbig)
-    assert_points_equal(big, rbig, "cloud_big (window path, mixed batch)")
+    assert_points_equal(big, rbig, f"cloud_big, empty frames {empty}, jump {jump}")
+    if len(rbig):
+        assert_points_equal(small, orc.downsample_pt_cloud(rbig, 0.05, True, 1)[0], "merge")
+    else:
+        assert len(small) == 0
 
 
-@pytest.mark.parametrize("jump,vs,rows,cols", [(1, 0.05, 720, 1280), (2, 0.05, 720, 1280), (3, 0.08, 333, 517), (2, 0.1, 97, 211)])
-def test_A7_window_path_equals_sort_path(orc, monkeypatch, jump, vs, rows, cols):
-    """same batch with and without the window path: identical bits (and both equal the oracle)"""
-    import online_3d_reconstruction_amd as o3dr
+def test_A6_single_frame_calls_around_an_empty_frame(ctx, orc, Q, frame_1248):
+    """single-frame API: an empty frame between two real ones leaves the context and its workspaces intact"""
+    disp, bgr = frame_1248
+    T = _pose(3)
+    ctx.set_camera(Q)
+    ctx.set_params(_params(jump_pixels=2, voxel_size=0.05))
+    ref = orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=2)[0]
+    assert_points_equal(ctx.createAndTransformPtCloud(disp, bgr, T), ref, "before")
+    assert len(ctx.createAndTransformPtCloud(np.zeros_like(disp), bgr, T)) == 0
+    assert_points_equal(ctx.createAndTransformPtCloud(disp, bgr, T), ref, "after")
+    assert len(ctx.voxelGrid(random_cloud(0, 1), (0.1, 0.1, 0.1), 0)) == 0
+
+
+def test_A1_general_Q_without_the_rectified_stereo_table(ctx, orc, frame_1249):
+    """a Q with entries outside the rectified-stereo pattern takes the per-pixel 4x4 fp64 product (no disparity table)"""
     from online_3d_reconstruction_amd import synth
-    Qs = synth.camera_Q(rows, cols)
-    F = 4
-    disp, bgr = synth.make_frames(40, F, rows, cols, invalid_frac=0.05)
-    rng = np.random.default_rng(jump)
-    disp[1] = rng.integers(60, 256, (rows, cols)).astype(np.uint8)  # every pixel its own depth level
-    poses = synth.make_poses(40, F)
-    out = []
-    for env in ("1", "0"):
-        monkeypatch.setenv("O3DR_WINDOW", env)
-        with o3dr.Context(0, Q=Qs, params=o3dr.Params(jump_pixels=jump, voxel_size=vs)) as c:
-            c.profileReset()
-            c.accumulateFrames(disp, bgr, poses)
-            out.append((c.cloudBigRead(), c.profileStats4()[3]))
-    assert out[0][1] > 0 and out[1][1] == 0
-    assert_points_equal(out[0][0], out[1][0], "window path vs sort path")
-    rbig = np.concatenate([orc.create_and_transform_pt_cloud(disp[i], bgr[i], Qs, poses[i], vs, jump_pixels=jump)[0]
-                           for i in range(F)])
-    assert_points_equal(out[0][0], rbig, "window path vs oracle")
+    disp, bgr = frame_1249
+    Qg = synth.camera_Q().copy()
+    Qg[0, 1] = 1e-3   # skew
+    Qg[1, 2] = -2e-4  # y depends on the disparity
+    Qg[3, 0] = 1e-6   # w depends on x
+    try:
+        ctx.set_camera(Qg)
+        for jump in (1, 3):
+            ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05))
+            got = ctx.createSingleImgPtCloud(disp, bgr)
+            assert_points_equal(got, orc.create_single_img_pt_cloud(disp, bgr, Qg, jump_pixels=jump), f"general Q, jump {jump}")
+            T = _pose(4)
+            got6 = ctx.createAndTransformPtCloud(disp, bgr, T)
+            assert_points_equal(got6, orc.create_and_transform_pt_cloud(disp, bgr, Qg, T, 0.05, jump_pixels=jump)[0], "A6 general Q")
+    finally:
+        ctx.set_camera(synth.camera_Q())
 
 
 def test_A1_row_pitch_larger_than_width(ctx, orc, Q, frame_1249):
@@ -670,7 +683,7 @@ def test_seven_threads_one_context_each_plus_concurrent_merge(orc, Q, frame_1248
     from online_3d_reconstruction_amd import synth
     frames = [frame_1248, frame_1249] + [synth.make_frame(i, invalid_frac=0.02) for i in range(5)]
     poses = synth.make_poses(20, 7)
-    params = o3dr.Params(jump_pixels=3, voxel_size=0.05)
+    params = _params(jump_pixels=3, voxel_size=0.05)
     merge_in = random_cloud(200000, 5)
     results, errors = [None] * 8, []
 
@@ -868,7 +881,7 @@ def test_error_behaviour_of_the_c_abi(Q, frame_1249):
         h = c._h
         assert call(h) == L.ERR_NOT_CONFIGURED and n.value == 0                   # camera not set
         c.set_camera(Q)
-        c.set_params(o3dr.Params(jump_pixels=1, voxel_size=0.05))
+        c.set_params(_params(jump_pixels=1, voxel_size=0.05))
         assert call(h, d=None) == L.ERR_INVALID_ARG and n.value == 0              # NULL image
         assert call(h, dp=1279) == L.ERR_INVALID_ARG and n.value == 0             # pitch smaller than a row
         assert call(h, rows=0) == L.ERR_INVALID_ARG and n.value == 0
