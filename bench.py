@@ -202,22 +202,24 @@ def main():
     m1_total, m2 = state["m1_total"], state["m2"]
 
     # ---- algorithmic bytes per step (DESIGN.md "Kernels and rooflines") --------------------------------
-    rec_passes, vox_in, vox_out, win_frames, sort_recs = (v / args.steps for v in stats[:5])  # device counters, per step
+    rec_passes, vox_in, vox_out, bk_frames, sort_recs = (v / args.steps for v in stats[:5])  # device counters, per step
     nv = n_valid_total  # valid points of this rank's frames (per step)
     merge_n = m1_total // world  # points entering the combined merge on this rank (its index slice)
     m1 = m1_total // world       # per-frame voxels of this rank's frames
-    fw = min(1.0, win_frames / F)  # share of the frames on the pixel-window path (voxels formed in image tiles)
-    fg = 1.0 - fw
+    fb = min(1.0, bk_frames / F)  # share of the frames that stayed on the bucketed path (the rest: sort-based kernels)
+    fs = 1.0 - fb
     merge_in = vox_in - nv       # points that entered whole-cloud grids (the merge), not per-frame ones
     bytes_per_step = {
-        "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate (+ the frame's bounding box)
-        "reproject_emit": fg * (4 * n_cand * F + 16 * nv),     # sort path: 1 B disparity + 3 B colour in, 16 B point out
-        "window_group": fw * (4 * n_cand * F + 20 * m1),       # window path: same pixels in, (index, centroid) per voxel out
-        "voxel_keys": 20 * (fg * nv + merge_in),               # 16 B point in, 4 B index out
+        "reproject_count": fs * 1 * n_cand * F,                # sort path: 1 B disparity per candidate
+        "reproject_emit": fs * (4 * n_cand * F + 16 * nv),     # sort path: 1 B disparity + 3 B colour in, 16 B point out
+        "bucket_plan": 1 * n_cand * F / 64,                    # 1/64 sample of the disparity bytes
+        "bucket_emit": 4 * n_cand * F + fb * 16 * nv,          # THE pass over the pixels: 4 B in, 16 B point out (partitioned)
+        "bucket_voxels": fb * (16 * nv + 16 * m1),             # partitioned points in, per-frame voxels out
+        "voxel_keys": 20 * (fs * nv + merge_in),               # 16 B point in, 4 B index out
         "radix_hist": 4 * rec_passes,                          # 4 B index per record per pass
         "radix_scatter": 16 * rec_passes - 4 * sort_recs,      # (index,id) in and out; pass 0 has no id to read
-        "run_segments": 8 * (fg * nv + merge_in) + 4 * vox_out,  # index read twice, run starts written
-        "centroid": fg * (20 * nv + 16 * m1) + fw * 36 * m1,   # sort path: id + gathered point in, centroid out; window path: id + record in, point out
+        "run_segments": 8 * (fs * nv + merge_in) + 4 * vox_out,  # index read twice, run starts written
+        "centroid": fs * (20 * nv + 16 * m1),                  # sort path: id + gathered point in, centroid out
         "centroid_runs": 16 * merge_n + 16 * m2,               # merge: points in (runs are contiguous), cells out
     }
     dom_name = L.KERNEL_NAMES[dom]
@@ -274,7 +276,7 @@ def main():
                        "bytes_per_frame": int(b_frame), "bytes_final_merge": int(b_final)},
         "kernel_ms_per_step": {k: round(v[0], 3) for k, v in per_kernel.items()},
         "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes),
-                 "frames_on_window_path_per_step": int(win_frames)},
+                 "frames_on_bucketed_path_per_step": int(bk_frames)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:

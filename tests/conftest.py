@@ -49,6 +49,19 @@ def frame_1249():
 
 
 @pytest.fixture(scope="session")
+def frame_1239():
+    return load_frame("1239")
+
+
+# Outputs of the reference ITSELF for this path: /root/reference/build/output/log.txt:39-44 prints, for six consecutive
+# accepted frames of a run that started at 1248, `disp_img_var` = Pose::getVariance (pose_functions.cpp:1007-1028) with
+# ostream's default 6 significant digits.  Indices 0, 1, 3 are frames whose disparity PNG is bundled.  (The same log's
+# `point_clout_pts: 747674 ...` lines are from an older ROI revision - the current loops give 748 000 candidates, all
+# valid on 1248 - and pin nothing.)
+REFERENCE_LOG_DISP_IMG_VAR = {"1248": "2.27913", "1249": "2.64813", "1251": "2.08488"}
+
+
+@pytest.fixture(scope="session")
 def ctx(Q):
     """A libo3dr context on cuda:0 (gpu tests only)."""
     import online_3d_reconstruction_amd as o3dr

@@ -45,8 +45,10 @@ def main():
     d, c = load_pair("B")
     np.savez_compressed(f"{OUT}/frame_B.npz", disp=d, bgr=c)
 
-    # two real frames inside config 1's range that have both image and disparity
-    for name in ("1248", "1249"):
+    # all seven real frames inside config 1's range (1230-1280) that have both image and disparity.  1239 and 1240
+    # carry the only real invalid pixels (11 759 / 1 978 in the ROI) and are rejected by the variance gate of
+    # pose.cpp:187-196; the other five are what config 1 really accepts.
+    for name in ("1239", "1240", "1246", "1248", "1249", "1251", "1255"):
         d, c = load_pair(name)
         np.savez_compressed(f"{OUT}/frame_{name}.npz", disp=d, bgr=c)
 

@@ -487,7 +487,8 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
     assert_points_equal(small, rsmall, "cloud_small (streamed host input)")
 
 
-@pytest.mark.parametrize("env", [{"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_NO_CLOUD_BOX": "1"}])
+@pytest.mark.parametrize("env", [{"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_NO_CLOUD_BOX": "1"},
+                                 {"O3DR_BUCKETS": "0"}])
 def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     """the switches a context reads at creation (per-point instead of per-run merge and the reverse, small launch
     groups, bounding box by a pass over the cloud) give the same bits"""
@@ -673,6 +674,34 @@ def test_disparity_variance_gate(ctx, orc, frame_1248, frame_1249):
     assert np.array_equal(got, got_dev)
     assert ref[3] == 0.0 and got[3] == 0.0
     assert np.array_equal(got > 5.0, ref > 5.0)  # the decision of pose.cpp:189
+
+
+def test_disparity_variance_equals_the_reference_runs_own_log(ctx):
+    """o3dr_disparity_variance against the values the reference itself logged for frames 1248, 1249, 1251
+    (/root/reference/build/output/log.txt:39-44, `disp_img_var`, 6 significant digits)"""
+    from conftest import REFERENCE_LOG_DISP_IMG_VAR, load_frame
+    ctx.set_params(_params(jump_pixels=15, voxel_size=0.05))
+    names = list(REFERENCE_LOG_DISP_IMG_VAR)
+    got = ctx.disparityVariance(np.stack([load_frame(n)[0] for n in names]))
+    for n, v in zip(names, got):
+        assert f"{v:.6g}" == REFERENCE_LOG_DISP_IMG_VAR[n], (n, v)
+
+
+@pytest.mark.parametrize("jump", [1, 15])
+def test_A1_A6_real_frame_with_invalid_pixels(ctx, orc, Q, frame_1239, jump):
+    """frame 1239: 11 759 invalid ROI pixels, the only REAL data that exercises the ordered compaction"""
+    disp, bgr = frame_1239
+    ctx.set_camera(Q)
+    ctx.set_params(_params(jump_pixels=jump, voxel_size=0.05))
+    ref = orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=jump)
+    if jump == 1:
+        assert len(ref) == 748000 - 11759
+    assert_points_equal(ctx.createSingleImgPtCloud(disp, bgr), ref, f"A1 frame 1239 jump {jump}")
+    T = _pose(12)
+    got, st = ctx.createAndTransformPtCloud(disp, bgr, T, return_status=True)
+    r6, rst = orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=jump)
+    assert st == rst
+    assert_points_equal(got, r6, f"A6 frame 1239 jump {jump}")
 
 
 def test_seven_threads_one_context_each_plus_concurrent_merge(orc, Q, frame_1248, frame_1249):

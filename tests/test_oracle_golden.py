@@ -338,3 +338,23 @@ def test_disparity_variance_matches_numpy(orc, frame_1248):
     got = orc.disparity_variance(disp)
     assert abs(got - var) <= 1e-9 * var
     assert got < 5.0 or got >= 5.0  # (the gate of pose.cpp:187-196 compares against 5)
+
+
+def test_disparity_variance_equals_the_reference_runs_own_log(orc):
+    """The one reference-held output on this path: `disp_img_var` of frames 1248, 1249, 1251 as the reference itself
+    logged them (/root/reference/build/output/log.txt:39-44, 6 significant digits).  Pins orc_disparity_variance, and
+    through it (tests/test_gpu_parity.py) o3dr_disparity_variance."""
+    from conftest import REFERENCE_LOG_DISP_IMG_VAR, load_frame
+    for name, logged in REFERENCE_LOG_DISP_IMG_VAR.items():
+        got = orc.disparity_variance(load_frame(name)[0])
+        assert f"{got:.6g}" == logged, (name, got, logged)
+
+
+def test_variance_gate_on_the_seven_bundled_frames_of_config1(orc):
+    """pose.cpp:187-196 rejects a frame iff disp_img_var > 5: of the seven frames bundled in 1230-1280, 1239 and
+    1240 are rejected (27.2 and 18.7, large invalid regions), the other five accepted"""
+    from conftest import load_frame
+    var = {n: orc.disparity_variance(load_frame(n)[0]) for n in ("1239", "1240", "1246", "1248", "1249", "1251", "1255")}
+    assert [n for n, v in var.items() if v > 5] == ["1239", "1240"], var
+    invalid = {n: int((load_frame(n)[0][20:700, 160:1260] <= 64).sum()) for n in ("1239", "1240", "1246")}
+    assert invalid == {"1239": 11759, "1240": 1978, "1246": 0}
