@@ -50,14 +50,14 @@ struct VoxelGeom {
 // kBkTarget points (splitters from a 1/64 sample of the frame), each bucket is then sorted, segmented and averaged
 // inside LDS by one workgroup.  Frames the scheme cannot take (see BK_MODE_*) go through the sort-based path.
 constexpr int kBkMaxBuckets = 1024;      // bucket ids 0..1022; 1023 marks an invalid pixel inside the kernels
-constexpr int kBkSlot = 4096;            // capacity (points) of a bucket's slot in HBM = largest bucket one workgroup sorts
-constexpr int kBkOversample = 24;        // samples per bucket
+constexpr int kBkSlot = 2048;            // capacity (points) of a bucket's slot in HBM = largest bucket one workgroup takes
+constexpr int kBkOversample = 14;        // samples per bucket (x 64: ~900 points; 2048 is +4.8 sigma of the sampling noise)
 constexpr int kBkSampleStride = 64;      // one sample per this many candidates (power of two; grows for huge frames)
 constexpr int kBkMaxSamples = 16384;     // samples one workgroup sorts (1024 threads x 16)
 constexpr int kBkEmitThreads = 256;      // partition kernel: 256 threads x 16 candidates = 4096-candidate tiles
 constexpr int kBkPerLane = 16;
 constexpr int kBkTile = kBkEmitThreads * kBkPerLane;
-constexpr int kBkVoxThreads = 256;       // bucket kernel: 256 threads x 8 or 16 records
+constexpr int kBkVoxThreads = 256;       // bucket kernel: 256 threads x 8 points = one slot
 constexpr uint32_t BK_MODE_RANGE = 1u;      // a point outside the packed coordinate range derived from the sample
 constexpr uint32_t BK_MODE_SLOT = 2u;       // a bucket outgrew its slot (heavy voxel or a sample that missed a cluster)
 constexpr uint32_t BK_MODE_PLAN = 4u;       // coordinates need more than 64 bits, or the sample already shows PCL's overflow
