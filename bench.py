@@ -48,6 +48,18 @@ def generate_frames(start, count, rows, cols, invalid, workers):
     return disp, bgr
 
 
+def kernel_sources_sha1():
+    """hash of the device sources: ties a PMC traffic file to the kernels it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "online_3d_reconstruction_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) +
+                       glob.glob(os.path.join(base, "kernels", "*.inc"))):
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def cpu_baseline(disp, bgr, poses, Q, voxel_size, jump, threads, n_frames, sor=False):
     """The CPU oracle (a port of the reference arithmetic, oracle/) timed on this host: A6 for
     n_frames frames on `threads` frame-parallel POSIX threads — the reference's own fan-out
@@ -67,6 +79,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=200, help="frames per GPU (weak scaling)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="total frames over all GPUs (strong scaling; BASELINE configs[2]: --total-frames 2000 on 8 GPUs); "
+                         "overrides --frames with total/N per GPU")
     ap.add_argument("--rows", type=int, default=720)
     ap.add_argument("--cols", type=int, default=1280)
     ap.add_argument("--jump-pixels", type=int, default=1)
@@ -77,7 +92,10 @@ def main():
                                                       "path, pose_functions.cpp:1673-1686); off in the headline config")
     ap.add_argument("--blur-kernel", type=int, default=1, help="> 1: bilateral filter on every disparity image first "
                     "(--blur_kernel of the reference, README.md:50 uses 30); informational, implies --no-cpu-baseline")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (cpu_baseline AND the bit-for-bit "
+                    "verification of the GPU clouds against the oracle, which reuses it)")
+    ap.add_argument("--no-pcie-step", action="store_true", help="skip the extra untimed step with HOST inputs "
+                    "(pcie_inclusive_frames_per_sec)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand the library HOST buffers (frames cross PCIe inside the timed region); reported as "
                          "metric frames_per_sec_pcie_inclusive, never the headline value")
@@ -98,6 +116,12 @@ def main():
 
     # ---- inputs (host) -----------------------------------------------------------------------------
     from online_3d_reconstruction_amd import synth
+    scaling = "weak"
+    if args.total_frames > 0:
+        if args.total_frames % world:
+            sys.exit("--total-frames must be a multiple of the number of GPUs")
+        args.frames = args.total_frames // world
+        scaling = "strong"
     F = args.frames
     first = rank * F  # contiguous block of frames per rank
     disp_h, bgr_h = generate_frames(first, F, args.rows, args.cols, args.invalid_frac, args.gen_workers)
@@ -202,24 +226,19 @@ def main():
     m1_total, m2 = state["m1_total"], state["m2"]
 
     # ---- algorithmic bytes per step (DESIGN.md "Kernels and rooflines") --------------------------------
-    rec_passes, vox_in, vox_out, bk_frames, sort_recs = (v / args.steps for v in stats[:5])  # device counters, per step
+    rec_passes, vox_in, vox_out, _unused, sort_recs = (v / args.steps for v in stats[:5])  # device counters, per step
     nv = n_valid_total  # valid points of this rank's frames (per step)
     merge_n = m1_total // world  # points entering the combined merge on this rank (its index slice)
     m1 = m1_total // world       # per-frame voxels of this rank's frames
-    fb = min(1.0, bk_frames / F)  # share of the frames that stayed on the bucketed path (the rest: sort-based kernels)
-    fs = 1.0 - fb
     merge_in = vox_in - nv       # points that entered whole-cloud grids (the merge), not per-frame ones
     bytes_per_step = {
-        "reproject_count": fs * 1 * n_cand * F,                # sort path: 1 B disparity per candidate
-        "reproject_emit": fs * (4 * n_cand * F + 16 * nv),     # sort path: 1 B disparity + 3 B colour in, 16 B point out
-        "bucket_plan": 1 * n_cand * F / 64,                    # 1/64 sample of the disparity bytes
-        "bucket_emit": 4 * n_cand * F + fb * 16 * nv,          # THE pass over the pixels: 4 B in, 16 B point out (partitioned)
-        "bucket_voxels": fb * (16 * nv + 16 * m1),             # partitioned points in, per-frame voxels out
-        "voxel_keys": 20 * (fs * nv + merge_in),               # 16 B point in, 4 B index out
+        "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate
+        "reproject_emit": 4 * n_cand * F + 16 * nv,            # 1 B disparity + 3 B colour in, 16 B point out
+        "voxel_keys": 20 * (nv + merge_in),                    # 16 B point in, 4 B index out
         "radix_hist": 4 * rec_passes,                          # 4 B index per record per pass
         "radix_scatter": 16 * rec_passes - 4 * sort_recs,      # (index,id) in and out; pass 0 has no id to read
-        "run_segments": 8 * (fs * nv + merge_in) + 4 * vox_out,  # index read twice, run starts written
-        "centroid": fs * (20 * nv + 16 * m1),                  # sort path: id + gathered point in, centroid out
+        "run_segments": 8 * (nv + merge_in) + 4 * vox_out,     # index read twice, run starts written
+        "centroid": 20 * nv + 16 * m1,                         # id + gathered point in, centroid out
         "centroid_runs": 16 * merge_n + 16 * m2,               # merge: points in (runs are contiguous), cells out
     }
     dom_name = L.KERNEL_NAMES[dom]
@@ -246,12 +265,16 @@ def main():
         del src_t, dst_t
     except Exception:
         roofline["measured_copy_GBps"] = None
-    traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    # HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+    # MI355X_MICROARCH.md "HBM"); only reported when that file was measured on the same kernel sources as this run
+    traffic_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    roofline["traffic_source"] = None
     if os.path.exists(traffic_file):
         try:
             tj = json.load(open(traffic_file))
-            if tj.get("kernel") == dom_name:
+            if tj.get("kernel") == dom_name and tj.get("kernel_sources_sha1") == kernel_sources_sha1():
                 roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command)"
         except Exception:
             pass
     # SURVEY 8d end-to-end figure: B_frame = 4N + 16Nv + 16Nv + 16M1 per frame, B_final = 16 SUM(M1) + 16 M2
@@ -262,7 +285,7 @@ def main():
     result = {
         "metric": "frames_per_sec_pcie_inclusive" if args.host_inputs else "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: gloo, one GPU)" if rehearsal else ""),
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: gloo, one GPU)" if rehearsal else ""),
         "config": {"workload": f"synthetic {args.cols}x{args.rows} dense stereo, jump_pixels {args.jump_pixels}, "
                                f"{F} frames/GPU, voxel_size {args.voxel_size}, min_points_per_voxel {args.min_points}, "
                                f"SOR {'on' if args.sor else 'off'}, " + (f"blur_kernel {args.blur_kernel}, " if args.blur_kernel > 1 else "") + f"frames resident in HBM (BASELINE.json configs[1])",
@@ -275,9 +298,40 @@ def main():
         "end_to_end": {"algorithmic_GBps": round(e2e_gbs, 2), "frac_of_hbm_peak": round(e2e_gbs / HBM_PEAK_GBS / world, 5),
                        "bytes_per_frame": int(b_frame), "bytes_final_merge": int(b_final)},
         "kernel_ms_per_step": {k: round(v[0], 3) for k, v in per_kernel.items()},
-        "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes),
-                 "frames_on_bucketed_path_per_step": int(bk_frames)},
+        "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes)},
     }
+
+    # ---- PCIe-inclusive rate: one extra, untimed-in-`value` step with HOST (pageable numpy) inputs -----------------
+    if world == 1 and not args.host_inputs and not args.no_pcie_step:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.cloudBigReset()
+        ctx.accumulateFrames(disp_h, bgr_h, poses_h)
+        ctx.finalize(device=dev)
+        torch.cuda.synchronize()
+        result["pcie_inclusive_frames_per_sec"] = round(F / (time.perf_counter() - t0), 2)
+
+    # ---- verification: the whole step of the headline config against the oracle, bit for bit -----------------------
+    result["verified"] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
+        from oracle import orc
+        ctx.cloudBigReset()
+        ctx.accumulateFrames(disp, bgr, poses)
+        big = ctx.cloudBigRead()
+        small = o3dr.api.points_from_torch(ctx.finalize(device=dev))
+        t0 = time.perf_counter()
+        rbig, rsmall = orc.run_frames(disp_h, bgr_h, Q, poses_h, args.voxel_size, jump_pixels=args.jump_pixels,
+                                      min_points_per_voxel=args.min_points, sor=args.sor, threads=args.cpu_threads)
+        t_or = time.perf_counter() - t0
+        ok_big = len(big) == len(rbig) and np.array_equal(big.view(np.uint32), rbig.view(np.uint32))
+        ok_small = len(small) == len(rsmall) and np.array_equal(small.view(np.uint32), rsmall.view(np.uint32))
+        result["verified"] = bool(ok_big and ok_small)
+        result["verification"] = {"against": "oracle/o3dr_oracle.c (orc_run_frames) on the identical frames and poses",
+                                  "cloud_big_points": int(len(big)), "oracle_cloud_big_points": int(len(rbig)),
+                                  "cloud_big_bit_equal": bool(ok_big), "merged_points": int(len(small)),
+                                  "oracle_merged_points": int(len(rsmall)), "merged_bit_equal": bool(ok_small),
+                                  "oracle_seconds": round(t_or, 2)}
+        del big, rbig
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
         nf = min(args.cpu_frames, F)
@@ -303,6 +357,8 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if result.get("verified") is False:
+        sys.exit("bench.py: the GPU clouds differ from the oracle's (see `verification` in the JSON line)")
 
 
 if __name__ == "__main__":

@@ -265,10 +265,7 @@ int o3dr_cloud_big_adopt(o3dr_ctx* ctx, int64_t n_points);
 #define O3DR_K_CENTROID     6  /* ordered per-voxel sums -> centroid */
 #define O3DR_K_OTHER        7  /* scans, grid setup, copies */
 #define O3DR_K_CENTROID_RUNS 8 /* ordered per-voxel sums over runs of points (whole-cloud calls) */
-#define O3DR_K_BUCKET_PLAN   9  /* bucketed A6 batches: 1/64 sample of a frame + splitters */
-#define O3DR_K_BUCKET_EMIT   10 /* bucketed A6 batches: fused reproject + SE(3) + stable partition into buckets */
-#define O3DR_K_BUCKET_VOXELS 11 /* bucketed A6 batches: per-bucket sort + ordered sums + centroid in LDS */
-#define O3DR_K_NUM          12
+#define O3DR_K_NUM          9
 /* Bracket every launch of kernel `kernel_id` (or all kernels if -1) with HIP events on the
  * context's stream; 0 launches are bracketed when disabled (the default). */
 int o3dr_profile_enable(o3dr_ctx* ctx, int32_t kernel_id, int32_t enable);
@@ -277,9 +274,8 @@ int o3dr_profile_read(o3dr_ctx* ctx, int32_t kernel_id, double* total_ms, int64_
 int o3dr_profile_reset(o3dr_ctx* ctx);
 /* Synchronises; counters since the last o3dr_profile_reset, for algorithmic-byte accounting:
  * out[0] = sum over voxel grids of (records x radix passes actually run), out[1] = points that entered
- * voxel grids, out[2] = points that left them, out[3] = frames of o3dr_accumulate_frames batches that stayed on the
- * bucketed path (the others were redone by the sort-based kernels), out[4] = records that entered the global sorts
- * (points or runs of points), out[5..7] = 0. */
+ * voxel grids, out[2] = points that left them, out[3] = 0, out[4] = records that entered the sorts (points or runs
+ * of points), out[5..7] = 0. */
 int o3dr_profile_stats(o3dr_ctx* ctx, int64_t out[8]);
 /* device name / arch / CU count of the context's device, for bench headers */
 int o3dr_device_info(o3dr_ctx* ctx, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes);

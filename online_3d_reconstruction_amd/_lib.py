@@ -14,10 +14,9 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_NOT_CONFIGURED, ERR_A
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_VOXEL_OVERFLOW = 1
 STATUS_INTERNAL = 0x80000000
-(K_COUNT, K_REPROJECT, K_KEYGEN, K_SORT_HIST, K_SORT_SCATTER, K_SEGMENT, K_CENTROID, K_OTHER, K_CENTROID_RUNS, K_BUCKET_PLAN,
- K_BUCKET_EMIT, K_BUCKET_VOXELS) = range(12)
+K_COUNT, K_REPROJECT, K_KEYGEN, K_SORT_HIST, K_SORT_SCATTER, K_SEGMENT, K_CENTROID, K_OTHER, K_CENTROID_RUNS = range(9)
 KERNEL_NAMES = ["reproject_count", "reproject_emit", "voxel_keys", "radix_hist", "radix_scatter", "run_segments",
-                "centroid", "other", "centroid_runs", "bucket_plan", "bucket_emit", "bucket_voxels"]
+                "centroid", "other", "centroid_runs"]
 
 
 class O3drError(RuntimeError):

@@ -72,10 +72,8 @@ struct o3dr_ctx {
     size_t ws_pts_elems = 0;
     int ws_frames = 0;
     size_t ws_emit_tiles = 0, ws_sort_tiles = 0, ws_seg_tiles = 0, ws_mm_floats = 0;
-    DevBuf ws_block, ws_pts_block, ws_sor_block, ws_bk_block;
+    DevBuf ws_block, ws_pts_block, ws_sor_block;
     int64_t ws_sor_cap = 0;
-    int ws_bk_frames = 0, ws_bk_nbmax = 0, ws_bk_tiles = 0;
-    int bucket_path = 1;  // O3DR_BUCKETS=0: fused A6 batches always take the sort-based path
 
     // accumulating cloud (pose.cpp:434 cloud_big)
     o3dr_point* cloud_big = nullptr;
@@ -229,77 +227,6 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
     return O3DR_OK;
 }
 
-// Bucketed per-frame path (kernels/bucket.inc): can a batch of this frame shape use it, and with what table sizes?
-struct BucketShape {
-    bool ok;
-    int stride, nbmax, tiles;
-};
-static BucketShape bucket_shape(int64_t n_cand)
-{
-    BucketShape b;
-    b.stride = kBkSampleStride;
-    const int64_t samples = (n_cand + b.stride - 1) / b.stride;
-    b.nbmax = (int)((samples + kBkOversample - 1) / kBkOversample) + 2;
-    b.tiles = (int)((n_cand + kBkTile - 1) / kBkTile);
-    // one workgroup sorts a frame's sample; bucket ids take 10 bits; a frame that falls back parks its output in its slots
-    b.ok = n_cand > 0 && samples <= kBkMaxSamples && b.nbmax <= kBkMaxBuckets - 1 && b.tiles <= 1024 &&
-           (int64_t)b.nbmax * kBkSlot >= n_cand;
-    return b;
-}
-static size_t bucket_bytes_per_frame(const BucketShape& b)
-{
-    const size_t units = (size_t)b.nbmax;
-    return (size_t)kBkMaxSamples * 12 + units * ((size_t)kBkSlot * 16 + (size_t)b.tiles * 8 + 4 + 8 + 24) + 8192;
-}
-static int bk_ensure(o3dr_ctx* c, int frames, const BucketShape& b)
-{
-    if (frames <= c->ws_bk_frames && b.nbmax <= c->ws_bk_nbmax && b.tiles <= c->ws_bk_tiles) {
-        c->ws.bk_nbmax = c->ws_bk_nbmax;  // (tables are indexed with the allocated row counts)
-        c->ws.bk_tiles = b.tiles;
-        return O3DR_OK;
-    }
-    const int F = frames > c->ws_bk_frames ? frames : c->ws_bk_frames;
-    const int NB = b.nbmax > c->ws_bk_nbmax ? b.nbmax : c->ws_bk_nbmax;
-    const int NT = b.tiles > c->ws_bk_tiles ? b.tiles : c->ws_bk_tiles;
-    const size_t units = (size_t)F * NB;
-    size_t off = 0;
-    size_t o_slots = off; off += align256(units * kBkSlot * sizeof(o3dr_point));
-    size_t o_seg = off;   off += align256(units * NT * sizeof(uint2));
-    size_t o_samp = off;  off += align256((size_t)F * kBkMaxSamples * 3 * sizeof(int32_t));
-    size_t o_spl = off;   off += align256((size_t)F * kBkMaxBuckets * sizeof(uint32_t));
-    size_t o_fill = off;  off += align256(units * sizeof(uint32_t));
-    size_t o_state = off; off += align256((units + 1) * sizeof(unsigned long long));
-    size_t o_mm = off;    off += align256((units + (size_t)F * kBkCopyBlocks) * 6 * sizeof(float));
-    size_t o_plan = off;  off += align256((size_t)F * sizeof(BucketPlan));
-    size_t o_geom = off;  off += align256((size_t)F * sizeof(VoxelGeom));
-    size_t o_ns = off;    off += align256((size_t)F * 4);
-    size_t o_mode = off;  off += align256((size_t)F * 4);
-    size_t o_nv = off;    off += align256((size_t)F * 4);
-    size_t o_nfb = off;   off += align256((size_t)F * 4);
-    CHK(dev_ensure(c, c->ws_bk_block, off));
-    char* base = (char*)c->ws_bk_block.p;
-    Workspace& w = c->ws;
-    w.bk_slots = (o3dr_point*)(base + o_slots);
-    w.bk_seg = (uint2*)(base + o_seg);
-    w.bk_samples = (int32_t*)(base + o_samp);
-    w.bk_splitters = (uint32_t*)(base + o_spl);
-    w.bk_fill = (uint32_t*)(base + o_fill);
-    w.bk_state = (unsigned long long*)(base + o_state);
-    w.bk_mm = (float*)(base + o_mm);
-    w.bk_plan = (BucketPlan*)(base + o_plan);
-    w.bk_geom = (VoxelGeom*)(base + o_geom);
-    w.bk_nsamples = (uint32_t*)(base + o_ns);
-    w.bk_mode = (uint32_t*)(base + o_mode);
-    w.bk_nvalid = (uint32_t*)(base + o_nv);
-    w.bk_nout_fb = (uint32_t*)(base + o_nfb);
-    c->ws_bk_frames = F;
-    c->ws_bk_nbmax = NB;
-    c->ws_bk_tiles = NT;
-    w.bk_nbmax = NB;
-    w.bk_tiles = b.tiles;
-    return O3DR_OK;
-}
-
 // buffers of the statistical outlier removal (allocated on first use: the measured configs run without it)
 static int sor_ensure(o3dr_ctx* c, int64_t cap)
 {
@@ -398,8 +325,6 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;       // whole-cloud grids always sort points
     else if (ru_env && atoi(ru_env) == 2) c->use_runs = 2;  // ... always sort runs (default: decided per cloud on the device)
     if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
-    const char* bk_env = getenv("O3DR_BUCKETS");
-    if (bk_env && atoi(bk_env) == 0) c->bucket_path = 0;
     const char* env = getenv("O3DR_BATCH_FRAMES");
     if (env && atoi(env) > 0) c->max_batch = atoi(env) > 512 ? 512 : atoi(env);
     (void)cloud_box_clear(c);
@@ -415,7 +340,6 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     dev_release(c->ws_block);
     dev_release(c->ws_pts_block);
     dev_release(c->ws_sor_block);
-    dev_release(c->ws_bk_block);
     dev_release(c->st_disp);
     dev_release(c->st_bgr);
     dev_release(c->st_in);
@@ -1270,18 +1194,14 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         }
         return O3DR_OK;
     }
-    // bucketed path: dense or strided grid pass only (no keypoint pass in front of it), u8 disparities
-    const BucketShape bks = bucket_shape(g.n);
-    const bool use_buckets = c->bucket_path && bks.ok && !use_kp && !c->params.dont_downsample && !c->params.disparity_f64 &&
-                             c->params.jump_pixels >= 1;
     int B = n_frames < c->max_batch ? n_frames : c->max_batch;
-    {   // ~56 bytes of sort workspace per candidate point (+ the buckets' slots); keep a batch under 24 GiB of HBM (of 288)
-        const int64_t per_frame = 56 * cap + (1 << 20) + (use_buckets ? (int64_t)bucket_bytes_per_frame(bks) : 0);
-        const int64_t fit = ((int64_t)24 << 30) / per_frame;
+    {   // ~56 bytes of workspace per candidate point; keep a batch under 12 GiB of HBM (of 288)
+        const int64_t per_frame = 56 * cap + (1 << 20);
+        const int64_t fit = ((int64_t)12 << 30) / per_frame;
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }
     CHK(ws_ensure(c, B, cap, true));
-    if (use_buckets) CHK(bk_ensure(c, B, bks));
+
     const bool streaming = mem == O3DR_MEM_HOST;
     if (streaming) {
         // Host buffers: frames cross PCIe once.  Upload batch k+1 on a second stream while batch k
@@ -1326,13 +1246,11 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
                   bgr_frame_stride, rows, cols, g, cap);
         a.xf_mode = 2;
         a.poses = (const float*)poses_d;
-        if (!use_buckets) {
-            launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
-            if (use_kp)
-                launch_keypoint_pass(&c->prof, c->stream, a, kp_d, 0, c->ws.pts, c->ws.n_kp, c->ws.mm, kpoff_d + f0, nb);
-            launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
-                             c->ws.scan_partial);
-        }
+        launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
+        if (use_kp)
+            launch_keypoint_pass(&c->prof, c->stream, a, kp_d, 0, c->ws.pts, c->ws.n_kp, c->ws.mm, kpoff_d + f0, nb);
+        launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
+                         c->ws.scan_partial);
         VoxelArgs v;
         v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
         v.in = c->ws.pts;
@@ -1351,10 +1269,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         v.mm_used = a.n_tiles + 1;
         v.stats = c->stats_dev;
         v.use_runs = 0;
-        if (use_buckets)
-            launch_bucket_frames(&c->prof, c->stream, c->ws, a, v, bks.stride);
-        else
-            launch_voxel_grid(&c->prof, c->stream, c->ws, v);
+        launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         c->cloud_ub += (int64_t)nb * cap;
         if (streaming) HIPCHK(hipEventRecord(c->ev_done[slot], c->stream));
@@ -1655,7 +1570,7 @@ extern "C" int o3dr_profile_stats(o3dr_ctx* c, int64_t out[8])
     out[0] = (int64_t)c->stats_host->sort_record_passes;
     out[1] = (int64_t)c->stats_host->voxel_points_in;
     out[2] = (int64_t)c->stats_host->voxel_points_out;
-    out[3] = (int64_t)c->stats_host->bucket_frames;
+    out[3] = 0;
     out[4] = (int64_t)c->stats_host->sort_records;
     out[5] = out[6] = out[7] = 0;
     return O3DR_OK;

@@ -45,31 +45,6 @@ struct VoxelGeom {
     uint32_t val_bits;    // run-compressed sorts: payload = first point | (points - 1) << val_bits; 0: payload = record id
 };
 
-// ---- bucketed per-frame voxel grid (fused A6 batches; kernels/bucket.inc) ----------------------------------------
-// A frame's points are partitioned, in ONE pass that also does the reprojection, into key-ordered buckets of about
-// kBkTarget points (splitters from a 1/64 sample of the frame), each bucket is then sorted, segmented and averaged
-// inside LDS by one workgroup.  Frames the scheme cannot take (see BK_MODE_*) go through the sort-based path.
-constexpr int kBkMaxBuckets = 1024;      // bucket ids 0..1022; 1023 marks an invalid pixel inside the kernels
-constexpr int kBkSlot = 2048;            // capacity (points) of a bucket's slot in HBM = largest bucket one workgroup takes
-constexpr int kBkOversample = 14;        // samples per bucket (x 64: ~900 points; 2048 is +4.8 sigma of the sampling noise)
-constexpr int kBkSampleStride = 64;      // one sample per this many candidates (power of two; grows for huge frames)
-constexpr int kBkMaxSamples = 16384;     // samples one workgroup sorts (1024 threads x 16)
-constexpr int kBkEmitThreads = 256;      // partition kernel: 256 threads x 16 candidates = 4096-candidate tiles
-constexpr int kBkPerLane = 16;
-constexpr int kBkTile = kBkEmitThreads * kBkPerLane;
-constexpr int kBkVoxThreads = 256;       // bucket kernel: 256 threads x 8 points = one slot
-constexpr uint32_t BK_MODE_RANGE = 1u;      // a point outside the packed coordinate range derived from the sample
-constexpr uint32_t BK_MODE_SLOT = 2u;       // a bucket outgrew its slot (heavy voxel or a sample that missed a cluster)
-constexpr uint32_t BK_MODE_PLAN = 4u;       // coordinates need more than 64 bits, or the sample already shows PCL's overflow
-struct BucketPlan {  // per frame, written by k_bucket_splitters
-    int32_t org[3];        // packed coordinate a = floor(p_a * inv_a) - org[a], 0 <= a < 2^bits[a]
-    uint32_t bits[3];
-    uint32_t total_bits;   // bits[0] + bits[1] + bits[2] <= 64
-    uint32_t n_buckets;    // 1 .. kBkMaxBuckets - 1
-    uint32_t n_samples;
-    uint32_t pad[3];
-};
-
 // ---- statistical outlier removal (A3b): search grid + threshold, written by k_sor_plan / k_sor_threshold ----
 constexpr int kSorMeanK = 50;  // sor0.setMeanK(50), pose_functions.cpp:1681
 struct SorGeom {
@@ -133,22 +108,6 @@ struct Workspace {
     uint32_t* run_len = nullptr;   // frames*(cap+1)  run lengths in sorted order -> exclusive prefix (min_points > 1)
     uint32_t* n_runs = nullptr;    // frames
     VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of runs, records starting in buffer 1
-    // bucketed per-frame path (allocated by ws_ensure when the batch may use it)
-    int bk_nbmax = 0;                  // bucket rows per frame in the tables below
-    int bk_tiles = 0;                  // partition tiles per frame (ceil(cap / kBkTile))
-    int32_t* bk_samples = nullptr;     // frames*kBkMaxSamples*3   sampled cell coordinates
-    uint32_t* bk_nsamples = nullptr;   // frames
-    BucketPlan* bk_plan = nullptr;     // frames
-    uint32_t* bk_splitters = nullptr;  // frames*kBkMaxBuckets     ascending 32-bit splitters, padded with 0xffffffff
-    uint32_t* bk_mode = nullptr;       // frames                   OR of BK_MODE_* (0: the frame stays on this path)
-    uint32_t* bk_fill = nullptr;       // frames*bk_nbmax          points in each bucket's slot
-    uint2* bk_seg = nullptr;           // frames*bk_nbmax*bk_tiles (start in slot, count) of tile t's run in bucket b
-    o3dr_point* bk_slots = nullptr;    // frames*bk_nbmax*kBkSlot  partitioned points
-    unsigned long long* bk_state = nullptr;  // frames*bk_nbmax + 1: chained-scan words of the bucket kernel, [last] = ticket counter
-    VoxelGeom* bk_geom = nullptr;      // frames: geometry of the frames on this path (ws.geom belongs to the sort-based path)
-    uint32_t* bk_nvalid = nullptr;     // frames
-    uint32_t* bk_nout_fb = nullptr;    // frames: outputs of frames that took the sort-based path inside a bucketed batch
-    float* bk_mm = nullptr;            // frames*(bk_nbmax + kBkCopyBlocks)*6 bounding boxes of what was appended
     float* out_mm = nullptr;         // frames*ceil(cap/256)*4*6: bounding boxes of what k_centroid's waves appended
     float* out_mm_partial = nullptr; // kBoxFoldBlocks*6
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
@@ -167,7 +126,7 @@ struct SortStats {
     uint64_t sort_record_passes;  // sum over voxel jobs of points * radix passes
     uint64_t voxel_points_in;     // points entering voxel grids (not counting overflow/passthrough)
     uint64_t voxel_points_out;    // points leaving them
-    uint64_t bucket_frames;       // frames of fused A6 batches that stayed on the bucketed path
+    uint64_t reserved;
     uint64_t sort_records;        // records entering the sorts (points, or runs of points)
     uint64_t pad[3];
 };
@@ -186,10 +145,9 @@ void launch_minmax_init(Profiler* pf, hipStream_t s, float* mm, int64_t mm_strid
 // keypoint pass of `frames` frames (one workgroup each); kp_off = nullptr: a single frame with n_kp keypoints
 void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,
                           o3dr_point* out, uint32_t* n_kp_out, float* mm, const int32_t* kp_off = nullptr, int frames = 1);
-// gate != nullptr: only frames with gate[f] != 0 or gate_geom[f].overflow are reprojected (the others count 0 points)
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
                       uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, float* mm,
-                      uint32_t* scan_partial, const uint32_t* gate = nullptr, const VoxelGeom* gate_geom = nullptr);
+                      uint32_t* scan_partial);
 void launch_transform(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t n, const float* T16_host,
                       o3dr_point* out);
 int launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
@@ -212,15 +170,9 @@ struct VoxelArgs {
     SortStats* stats; // optional device statistics
     int use_runs;     // sort runs of consecutive equal indices instead of points (whole-cloud calls)
     float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
-    int64_t out_frame_stride = 0;  // != 0: frame f's output goes to out_base + f*stride and cc is left alone
 };
-constexpr int kBkCopyBlocks = 64;     // workgroups per frame of the copy that moves a sort-path frame's output into place
 constexpr int kBoxFoldBlocks = 1024;  // workgroups (and partial boxes) of the running-bounding-box fold
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
-// A6 for a batch of frames on the bucketed path (frames it cannot take fall back to the sort-based kernels inside);
-// appends to v.out_base at cc->count in frame order like launch_voxel_grid.  `a` as for launch_reproject (xf_mode 2).
-void launch_bucket_frames(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, const VoxelArgs& v,
-                          int sample_stride);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);
 // cv::bilateralFilter on u8 images; tab = color_weight[256] | space_weight[maxk] | tile offsets [maxk] (device)
 constexpr int kBilMaxRadius = 64;

@@ -22,7 +22,6 @@
 //   radix_sort   digit histograms and the stable lane-counting scatter
 //   voxel_runs   run heads/starts, min_points filter, centroid kernels, run-compressed variants, running bbox
 //   multigpu     bounding-box fold, index-slice partition
-//   bucket       bucketed per-frame voxel grid of fused A6 batches (sample, splitters, partition, in-LDS buckets)
 //   sor          statistical outlier removal
 // The launchers follow in this file.
 #include "o3dr_device.h"
@@ -38,7 +37,6 @@ namespace o3dr {
 #include "kernels/radix_sort.inc"
 #include "kernels/voxel_runs.inc"
 #include "kernels/multigpu.inc"
-#include "kernels/bucket.inc"
 #include "kernels/sor.inc"
 
 // =================================================================================================
@@ -83,7 +81,7 @@ void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, c
 
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
                       uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, float* mm,
-                      uint32_t* scan_partial, const uint32_t* gate, const VoxelGeom* gate_geom)
+                      uint32_t* scan_partial)
 {
     if (a.n_tiles <= 0) {  // jump_pixels == 0: keypoints only
         ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -94,9 +92,9 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     {
         ProfScope ps(pf, O3DR_K_COUNT, s);
         if (a.disp_f64)
-            k_reproject_count<true><<<grid, kEmitThreads, 0, s>>>(a, tile_cnt, gate, gate_geom);
+            k_reproject_count<true><<<grid, kEmitThreads, 0, s>>>(a, tile_cnt);
         else
-            k_reproject_count<false><<<grid, kEmitThreads, 0, s>>>(a, tile_cnt, gate, gate_geom);
+            k_reproject_count<false><<<grid, kEmitThreads, 0, s>>>(a, tile_cnt);
     }
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -105,9 +103,9 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
         if (a.disp_f64)
-            k_reproject_emit<true><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, gate, gate_geom);
+            k_reproject_emit<true><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
         else
-            k_reproject_emit<false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, gate, gate_geom);
+            k_reproject_emit<false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
     }
 }
 
@@ -130,6 +128,16 @@ int launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int6
     ProfScope ps(pf, O3DR_K_OTHER, s);
     k_points_minmax<<<dim3(nblk, frames), kPtThreads, 0, s>>>(in, in_fstride, n_dev, mm_stride, mm);
     return nblk;  // slots written per frame
+}
+
+static int exp_align_shift()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("O3DR_EXP_ALIGN");
+        v = e ? atoi(e) : 14;
+    }
+    return v;
 }
 
 // The voxel grid proper.  Expects ws.mm slots [0, v.mm_used) of every frame to hold bounding boxes of
@@ -241,14 +249,15 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         k_frame_offsets<<<1, 256, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc,
-                                          v.stats, sort_geom, v.out_frame_stride);
+                                          v.stats, sort_geom);
     }
     const int nbx = cdiv64(cap, kPtThreads);
     if (cap > 0 && use_runs) {
         ProfScope ps(pf, O3DR_K_CENTROID_RUNS, s);
         k_centroid_runs<<<dim3(nbx, F), kPtThreads, 0, s>>>(
             v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, ws.run_start,
-            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.geom, ws.n_out, ws.out_off, v.z_offset, v.out_base, v.cc);
+            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.geom, ws.n_out, ws.out_off, v.z_offset, v.out_base, v.cc,
+            exp_align_shift());
     }
     if (cap > 0) {
         ProfScope ps(pf, O3DR_K_CENTROID, s);
@@ -268,79 +277,6 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         const int nbx = cdiv64(cap, kPtThreads) * (kPtThreads / 64);
         k_cloud_bbox_fold<<<kBoxFoldBlocks, 256, 0, s>>>(ws.out_mm, nbx, F, ws.n_out, ws.out_mm_partial);
         k_cloud_bbox_merge<<<1, 384, 0, s>>>(ws.out_mm_partial, kBoxFoldBlocks, v.cloud_box);
-    }
-}
-
-// A6 for `v.frames` frames on the bucketed path (kernels/bucket.inc).  `a` describes the frames (poses in HBM,
-// xf_mode 2, a.n_tiles/mm_stride of the SORT path's tiling: its reprojection is reused for frames that fall back).
-void launch_bucket_frames(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, const VoxelArgs& v,
-                          int sample_stride)
-{
-    const int F = v.frames;
-    const int nbmax = ws.bk_nbmax, bk_tiles = ws.bk_tiles;
-    const int n_cand = a.Ny * a.Nx;
-    const float inv0 = 1.0f / v.leaf[0], inv1 = 1.0f / v.leaf[1], inv2 = 1.0f / v.leaf[2];  // inverse_leaf_size_, as k_voxel_geom
-    const int64_t units = (int64_t)F * nbmax;
-    {
-        ProfScope ps(pf, O3DR_K_OTHER, s);
-        (void)hipMemsetAsync(ws.bk_nsamples, 0, sizeof(uint32_t) * F, s);
-        (void)hipMemsetAsync(ws.bk_fill, 0, sizeof(uint32_t) * units, s);
-        (void)hipMemsetAsync(ws.bk_seg, 0, sizeof(uint2) * units * bk_tiles, s);
-        (void)hipMemsetAsync(ws.bk_state, 0, sizeof(unsigned long long) * (units + 1), s);
-    }
-    {
-        ProfScope ps(pf, O3DR_K_BUCKET_PLAN, s);
-        const int n_blocks = cdiv64(n_cand, sample_stride);
-        k_bucket_sample<<<dim3(cdiv64(n_blocks, 256), F), 256, 0, s>>>(a, sample_stride, inv0, inv1, inv2, ws.bk_samples, ws.bk_nsamples);
-        k_bucket_splitters<<<F, kSplThreads, 0, s>>>(ws.bk_samples, ws.bk_nsamples, nbmax, ws.bk_plan, ws.bk_splitters, ws.bk_mode);
-    }
-    // the partition kernel tiles the candidates by kBkTile; bounding-box slots and tile counts use ITS tiling here
-    ReprojectArgs ab = a;
-    ab.n_tiles = bk_tiles;
-    {
-        ProfScope ps(pf, O3DR_K_BUCKET_EMIT, s);
-        k_bucket_emit<<<dim3(bk_tiles, F), kBkEmitThreads, 0, s>>>(ab, ws.bk_plan, ws.bk_splitters, ws.bk_mode, inv0, inv1, inv2,
-                                                                   ws.bk_fill, ws.bk_seg, ws.bk_slots, nbmax, ws.tile_cnt, ws.mm);
-    }
-    {
-        ProfScope ps(pf, O3DR_K_OTHER, s);
-        launch_scan(s, ws.tile_cnt, bk_tiles, bk_tiles, F, ws.bk_nvalid, nullptr, ws.scan_partial);
-        k_voxel_geom<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, bk_tiles, ws.bk_nvalid, v.leaf[0], v.leaf[1], v.leaf[2], 0.f, ws.bk_geom);
-    }
-    // frames that left the bucketed path (BK_MODE_*, or PCL's overflow guard): the sort-based kernels, gated to those
-    // frames, with each frame's output parked in its own (unused) slot area
-    launch_minmax_init(pf, s, ws.mm, ws.mm_stride, a.n_tiles, ws.n_kp, F);
-    launch_reproject(pf, s, a, F, ws.pts, ws.tile_cnt, ws.n_kp, ws.n_valid, ws.mm, ws.scan_partial, ws.bk_mode, ws.bk_geom);
-    {
-        VoxelArgs vf = v;
-        vf.in = ws.pts;
-        vf.in_fstride = v.cap;
-        vf.n_dev = ws.n_valid;
-        vf.out_base = ws.bk_slots;
-        vf.out_frame_stride = (int64_t)nbmax * kBkSlot;
-        vf.cloud_box = nullptr;
-        vf.mm_used = a.n_tiles + 1;
-        vf.use_runs = 0;
-        launch_voxel_grid(pf, s, ws, vf);
-        ProfScope ps(pf, O3DR_K_OTHER, s);
-        (void)hipMemcpyAsync(ws.bk_nout_fb, ws.n_out, sizeof(uint32_t) * F, hipMemcpyDeviceToDevice, s);
-    }
-    float* bk_mm = v.cloud_box ? ws.bk_mm : nullptr;
-    {
-        ProfScope ps(pf, O3DR_K_BUCKET_VOXELS, s);
-        k_bucket_voxels<<<(unsigned)units, kBkVoxThreads, 0, s>>>(ws.bk_slots, ws.bk_fill, ws.bk_seg, ws.bk_geom, ws.bk_mode, ws.bk_nout_fb,
-                                                                  nbmax, bk_tiles, F, ws.bk_state, v.out_base, v.cc, bk_mm);
-    }
-    {
-        ProfScope ps(pf, O3DR_K_OTHER, s);
-        k_bucket_finish<<<1, 256, 0, s>>>(ws.bk_state, nbmax, F, ws.bk_geom, ws.bk_mode, ws.bk_nvalid, ws.n_out, ws.out_off, v.cc, v.stats);
-        float* mm_fb = bk_mm ? bk_mm + units * 6 : nullptr;
-        k_bucket_copy_fb<<<dim3(kBkCopyBlocks, F), 256, 0, s>>>(ws.bk_slots, nbmax, ws.bk_geom, ws.bk_mode, ws.bk_nout_fb, ws.out_off,
-                                                              v.out_base, mm_fb);
-        if (v.cloud_box) {
-            k_bbox_fold_all<<<kBoxFoldBlocks, 256, 0, s>>>(bk_mm, units + (int64_t)F * kBkCopyBlocks, ws.out_mm_partial);
-            k_cloud_bbox_merge<<<1, 384, 0, s>>>(ws.out_mm_partial, kBoxFoldBlocks, v.cloud_box);
-        }
     }
 }
 

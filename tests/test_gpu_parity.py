@@ -487,8 +487,7 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
     assert_points_equal(small, rsmall, "cloud_small (streamed host input)")
 
 
-@pytest.mark.parametrize("env", [{"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_NO_CLOUD_BOX": "1"},
-                                 {"O3DR_BUCKETS": "0"}])
+@pytest.mark.parametrize("env", [{"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_NO_CLOUD_BOX": "1"}])
 def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     """the switches a context reads at creation (per-point instead of per-run merge and the reverse, small launch
     groups, bounding box by a pass over the cloud) give the same bits"""
