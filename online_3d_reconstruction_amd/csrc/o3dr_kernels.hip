@@ -130,16 +130,6 @@ int launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int6
     return nblk;  // slots written per frame
 }
 
-static int exp_align_shift()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("O3DR_EXP_ALIGN");
-        v = e ? atoi(e) : 14;
-    }
-    return v;
-}
-
 // The voxel grid proper.  Expects ws.mm slots [0, v.mm_used) of every frame to hold bounding boxes of
 // the (un-offset) inputs.
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v)
@@ -256,8 +246,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         ProfScope ps(pf, O3DR_K_CENTROID_RUNS, s);
         k_centroid_runs<<<dim3(nbx, F), kPtThreads, 0, s>>>(
             v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, ws.run_start,
-            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.geom, ws.n_out, ws.out_off, v.z_offset, v.out_base, v.cc,
-            exp_align_shift());
+            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.geom, ws.n_out, ws.out_off, v.z_offset, v.out_base, v.cc);
     }
     if (cap > 0) {
         ProfScope ps(pf, O3DR_K_CENTROID, s);
