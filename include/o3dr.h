@@ -15,8 +15,12 @@
  *   - every function returns O3DR_OK (0) or a negative O3DR_ERR_* code; on error
  *     every `n_out` is set to 0 ("output cloud left empty", pose.cpp:620-635).
  *   - `mem` says where ALL data pointers of that call live: O3DR_MEM_HOST
- *     (the library stages them through pinned buffers) or O3DR_MEM_DEVICE
- *     (HBM pointers of the context's device; nothing is copied).  Small
+ *     (copied into HBM staging buffers with hipMemcpyAsync straight from the
+ *     caller's pointers: page-locked caller memory transfers by DMA, pageable
+ *     memory goes through the HIP runtime's own bounce buffers; the batched
+ *     o3dr_accumulate_frames uploads batch k+1 on a second stream while batch
+ *     k computes) or O3DR_MEM_DEVICE (HBM pointers of the context's device;
+ *     nothing is copied).  Small
  *     parameter arrays (Q, poses of the single-frame calls, leaf) are always
  *     host pointers; the batched `o3dr_accumulate_frames` takes its pose array
  *     in `mem` like the images.

@@ -96,7 +96,9 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
     if status & 1:  # PCL's overflow guard on the global box: the merge returns its input unchanged
         counts = [0] * world
         counts[rank] = n_local  # everything stays where it is; rank order is already global order
-    zero_copy = comm_device is None and hasattr(ctx, "cloudBigView") and str(device).startswith("cuda")
+    # Streams: cloudBigPartition returns after its own stream has drained (it reads the counts back), so the
+    # collective below may run on any stream; it is drained in turn before the library adopts what it received.
+    zero_copy = comm_device is None and hasattr(ctx, "cloudBigView")
     if zero_copy:
         # send straight out of cloud_big, receive straight into the library's second cloud buffer
         send = ctx.cloudBigView()
@@ -107,7 +109,8 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
         n_recv = sum(recv_counts)
         recv = ctx.cloudBigRecvBuffer(n_recv)
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
-        torch.cuda.current_stream(device).synchronize()
+        if torch.device(device).type == "cuda":
+            torch.cuda.current_stream(device).synchronize()
         ctx.cloudBigAdopt(n_recv)
     else:
         send = ctx.cloudBigRead(device=device).to(cdev)

@@ -127,7 +127,24 @@ class CpuCtx:
         return torch.from_numpy(out.view(np.int32).reshape(-1, 4).copy())
 
 
-def _worker_partitioned(rank, world, port, out_dir):
+class CpuCtxZeroCopy(CpuCtx):
+    """+ the zero-copy plumbing of the real context (o3dr_cloud_big_view / _recv_buffer / _adopt): the send buffer IS
+    the cloud, the receive buffer belongs to the context, adopt makes its first n points the new cloud"""
+
+    def cloudBigView(self):
+        self._send = torch.from_numpy(self.cloud.view(np.int32).reshape(-1, 4))  # aliases the cloud: no copy
+        return self._send
+
+    def cloudBigRecvBuffer(self, n_points):
+        self._recv = torch.full((max(int(n_points), 1) + 3, 4), -1, dtype=torch.int32)  # (larger than asked, like the library's)
+        return self._recv[: int(n_points)]
+
+    def cloudBigAdopt(self, n_points):
+        assert 0 <= n_points <= self._recv.shape[0]
+        self.cloud = self._recv[: int(n_points)].numpy().view(self.orc.POINT).reshape(-1).copy()
+
+
+def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -140,21 +157,34 @@ def _worker_partitioned(rank, world, port, out_dir):
     F_total, rows, cols, jump, vs = 7, 240, 400, 2, 0.05
     Q = synth.camera_Q(rows, cols)
     a, b = o3dist.shard_range(F_total, rank, world)
-    ctx = CpuCtx(orc, vs)
+    ctx = (CpuCtxZeroCopy if zero_copy else CpuCtx)(orc, vs)
     for i in range(a, b):
         d, c = synth.make_frame(i, rows, cols)
         ctx.cloud = np.concatenate([ctx.cloud, orc.create_and_transform_pt_cloud(d, c, Q, synth.make_pose(i), vs, jump_pixels=jump)[0]])
+    n_before = len(ctx.cloud)
     merged, total = o3dist.merge_partitioned(ctx, torch.device("cpu"))
+    if zero_copy:  # counts matrix -> receive counts: what arrived is this rank's slice of everybody's cloud
+        sent = torch.tensor([n_before], dtype=torch.int64)
+        got = torch.tensor([len(ctx.cloud)], dtype=torch.int64)
+        dist.all_reduce(sent)
+        dist.all_reduce(got)
+        assert int(sent) == int(got) == total
     np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged.numpy().view(orc.POINT).reshape(-1))
     np.save(os.path.join(out_dir, f"total_{rank}.npy"), np.array([total]))
     dist.destroy_process_group()
 
 
-def test_partitioned_merge_equals_single_process(tmp_path, orc):
-    """3 ranks, 7 frames: slices exchanged all-to-all, merged locally, gathered == one-process merge"""
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_partitioned_merge_equals_single_process(tmp_path, orc, zero_copy):
+    """3 ranks, 7 frames: slices exchanged all-to-all, merged locally, gathered == one-process merge; with the copying
+    exchange (what a rehearsal over gloo uses) and with the zero-copy one the GPU path takes (send view, library-owned
+    receive buffer, adopt)"""
     from online_3d_reconstruction_amd import synth
     world = 3
-    mp.spawn(_worker_partitioned, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_partitioned, args=(world, _free_port(), str(tmp_path), zero_copy), nprocs=world, join=True)
     F_total, rows, cols, jump, vs = 7, 240, 400, 2, 0.05
     Q = synth.camera_Q(rows, cols)
     clouds = []
