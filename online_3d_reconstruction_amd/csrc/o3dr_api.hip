@@ -1247,11 +1247,18 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         a.xf_mode = 2;
         a.poses = (const float*)poses_d;
         launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
+        // no keypoint pass in front of the grid pass and a voxel grid behind it: index and first digit histogram are
+        // produced by the pass that writes the points (the keypoint pass would need them too: it keeps the two-step form)
+        const bool fused = !use_kp && !c->params.dont_downsample && a.n_tiles > 0;
         if (use_kp)
             launch_keypoint_pass(&c->prof, c->stream, a, kp_d, 0, c->ws.pts, c->ws.n_kp, c->ws.mm, kpoff_d + f0, nb);
-        launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
-                         c->ws.scan_partial);
+        if (fused)
+            launch_reproject_fused(&c->prof, c->stream, c->ws, a, nb, cap, leaf);
+        else
+            launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
+                             c->ws.scan_partial);
         VoxelArgs v;
+        v.keys_ready = fused ? 1 : 0;
         v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
         v.in = c->ws.pts;
         v.in_fstride = cap;

@@ -148,6 +148,11 @@ void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, c
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
                       uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, float* mm,
                       uint32_t* scan_partial);
+// A1 + A2 of a batch with the per-frame grid's index and first digit histogram produced in the same pass over the
+// pixels (bounding boxes and counts first, then PCL's geometry, then the points): for launch_voxel_grid with
+// v.keys_ready = 1.  No keypoint pass (n_kp must hold zeros).
+void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, int frames, int64_t cap,
+                            const float leaf[3]);
 void launch_transform(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t n, const float* T16_host,
                       o3dr_point* out);
 int launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,
@@ -170,6 +175,7 @@ struct VoxelArgs {
     SortStats* stats; // optional device statistics
     int use_runs;     // sort runs of consecutive equal indices instead of points (whole-cloud calls)
     float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
+    int keys_ready = 0;  // launch_reproject_fused ran: ws.geom, the indices in ws.keys[0] and the first histogram exist
 };
 constexpr int kBoxFoldBlocks = 1024;  // workgroups (and partial boxes) of the running-bounding-box fold
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);

@@ -103,9 +103,38 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
         if (a.disp_f64)
-            k_reproject_emit<true><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
+            k_reproject_emit<true, false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr, 0, nullptr, 0, nullptr);
         else
-            k_reproject_emit<false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm);
+            k_reproject_emit<false, false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr, 0, nullptr, 0, nullptr);
+    }
+}
+
+void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, int frames, int64_t cap,
+                            const float leaf[3])
+{
+    const dim3 grid(a.n_tiles, frames);
+    const int n_sort_tiles = cdiv64(cap, kSortTile);
+    {
+        ProfScope ps(pf, O3DR_K_COUNT, s);
+        if (a.disp_f64)
+            k_reproject_bbox_count<true><<<grid, kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
+        else
+            k_reproject_bbox_count<false><<<grid, kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
+    }
+    {
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        launch_scan(s, ws.tile_cnt, a.n_tiles, a.n_tiles, frames, ws.n_valid, ws.n_kp, ws.scan_partial);
+        k_voxel_geom<<<frames, 256, 0, s>>>(ws.mm, ws.mm_stride, a.n_tiles + 1, ws.n_valid, leaf[0], leaf[1], leaf[2], 0.f, ws.geom);
+        (void)hipMemsetAsync(ws.hist, 0, sizeof(uint32_t) * (size_t)frames * kMaxRadix * n_sort_tiles, s);
+    }
+    {
+        ProfScope ps(pf, O3DR_K_REPROJECT, s);
+        if (a.disp_f64)
+            k_reproject_emit<true, true><<<grid, kEmitThreads, 0, s>>>(a, ws.pts, ws.tile_cnt, ws.n_kp, ws.mm, ws.geom, cap, ws.keys[0],
+                                                                      n_sort_tiles, ws.hist);
+        else
+            k_reproject_emit<false, true><<<grid, kEmitThreads, 0, s>>>(a, ws.pts, ws.tile_cnt, ws.n_kp, ws.mm, ws.geom, cap, ws.keys[0],
+                                                                       n_sort_tiles, ws.hist);
     }
 }
 
@@ -138,7 +167,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     const int64_t cap = v.cap;
     const int n_sort_tiles = cdiv64(cap, kSortTile);
     const int n_seg_tiles = cdiv64(cap, kSegTile);
-    {
+    if (!v.keys_ready) {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         k_voxel_geom<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, v.mm_used, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2],
                                        v.z_offset, ws.geom);
@@ -150,7 +179,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     const VoxelGeom* sort_geom = use_runs ? ws.geom_runs : ws.geom;
     if (!v.passthrough && cap > 0) {
         const dim3 grid(n_sort_tiles, F);
-        {
+        if (!(v.keys_ready && !use_runs)) {
             ProfScope ps(pf, O3DR_K_KEYGEN, s);
             if (use_runs)  // indices and, in the same read, how many runs of equal indices start in every tile
                 k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
