@@ -12,12 +12,15 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(d, counter):
     out = collections.defaultdict(list)
-    for path in glob.glob(f"{d}/*/*counter_collection.csv"):
+    for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("o3dr::k_", "").split("<")[0]
@@ -37,7 +40,10 @@ def main():
         write = sum(w.get(k, [])) * 1024.0
         kernels[k] = {"launches": n, "fetch_bytes_per_launch": round(fetch / n), "write_bytes_per_launch": round(write / n),
                       "hbm_bytes_per_launch": round((fetch + write) / n)}
+    from bench import kernel_sources_sha1
     doc = {"kernel": bench_class, "kernel_symbol": "o3dr::k_" + dominant,
+           "kernel_sources_sha1": kernel_sources_sha1(),  # bench.py only reports this file's traffic for the same device sources
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-step",
            "hbm_bytes_per_launch": kernels.get(dominant, {}).get("hbm_bytes_per_launch"),
            "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes", "kernels": kernels}
     json.dump(doc, open(out_path, "w"), indent=1)
