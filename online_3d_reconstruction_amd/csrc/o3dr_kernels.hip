@@ -218,8 +218,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             }
             {
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
-                k_radix_scatter_lane<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                  sort_geom, pass, n_sort_tiles, ws.hist, ws.run_start);
+                k_radix_scatter_lane<<<dim3(cdiv64(n_sort_tiles, kScatterTilesPerWg), F), kSortThreads, 0, s>>>(
+                    ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, sort_geom, pass, n_sort_tiles, ws.hist, ws.run_start);
             }
         }
         const dim3 sgrid(n_seg_tiles, F);
@@ -363,8 +363,8 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     for (int pass = 0; pass < kMaxPasses; ++pass) {
         k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
         launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
-        k_radix_scatter_lane<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap,
-                                                                           ws.geom, pass, n_sort_tiles, ws.hist, nullptr);
+        k_radix_scatter_lane<<<dim3(cdiv64(n_sort_tiles, kScatterTilesPerWg), 1), kSortThreads, 0, s>>>(
+            ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, nullptr);
     }
     k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
                                                      ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);

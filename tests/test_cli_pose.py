@@ -165,15 +165,14 @@ def test_cli_keypoint_lists(tmp_path, orc, Q, extra):
     kps = {}
     for name, n in (("1248", 800), ("1249", 0)):
         kps[name] = np.column_stack([rng.uniform(-30, 1310, n), rng.uniform(-30, 750, n)]).astype(np.float32)
-        np.savetxt(f"{tmp}/kp/{name}.txt", kps[name], fmt="%.9g")
+        np.savetxt(f"{tmp}/kp/{name}.txt", kps[name], fmt="%.9g")  # (%.9g round-trips a float32 exactly)
     cmd = [POSE_BIN, "1248", "1249", "--jump_pixels", "15", "--voxel_size", "0.05", "--only_MAVLink", "--keypoints_dir", tmp + "/kp/",
            "--data_dir", tmp + "/data_files/", "--image_dir", tmp + "/images/", "--disparity_dir", tmp + "/disparities/",
            "--output_dir", tmp + "/output/"] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     got = _read_ply(tmp + "/output/cloud.ply")
-    clouds = [_oracle_frame(orc, Q, name, 15, True, kp_xy=np.loadtxt(f"{tmp}/kp/{name}.txt", np.float32, ndmin=2).reshape(-1, 2))
-              for name in ("1248", "1249")]
+    clouds = [_oracle_frame(orc, Q, name, 15, True, kp_xy=kps[name]) for name in ("1248", "1249")]
     inside = (kps["1248"][:, 0].astype(int) >= 160) & (kps["1248"][:, 0].astype(int) < 1260)
     assert 0 < inside.sum() < 800
     ref, _ = orc.downsample_pt_cloud(np.concatenate(clouds), 0.05, True, 1)
