@@ -101,6 +101,7 @@ struct o3dr_ctx {
     DevBuf st2_disp[2], st2_bgr[2], st2_poses[2];
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: consumed by the next voxel grid
     int host_batch = 32;  // frames per upload while the previous batch computes (O3DR_HOST_BATCH_FRAMES)
     Profiler prof;
 };
@@ -824,6 +825,8 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     v.mm_used = mm_used;
     v.stats = c->stats_dev;
     v.use_runs = c->use_runs;
+    v.test_corrupt = c->test_corrupt;
+    c->test_corrupt = 0;
     if (do_sor) {
         CHK(sor_ensure(c, n_in));
         v.mm_used = launch_sor(&c->prof, c->stream, c->ws, in_d, c->ws.n_valid, n_in, mm_used, 1.0, c->ws.sor_pts, c->ws.sor_n);
@@ -1536,6 +1539,13 @@ extern "C" int o3dr_disparity_variance(o3dr_ctx* c, const uint8_t* disp, int64_t
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(variance_out, var_d, sizeof(double) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_test_corrupt_next_gather(o3dr_ctx* c)
+{
+    CTX_ENTER(c);
+    c->test_corrupt = 1;
     return O3DR_OK;
 }
 

@@ -176,6 +176,7 @@ struct VoxelArgs {
     int use_runs;     // sort runs of consecutive equal indices instead of points (whole-cloud calls)
     float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
     int keys_ready = 0;  // launch_reproject_fused ran: ws.geom, the indices in ws.keys[0] and the first histogram exist
+    int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: poison one sorted payload before the gather (guard test)
 };
 constexpr int kBoxFoldBlocks = 1024;  // workgroups (and partial boxes) of the running-bounding-box fold
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);

@@ -271,6 +271,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                                           v.stats, sort_geom);
     }
     const int nbx = cdiv64(cap, kPtThreads);
+    if (v.test_corrupt && cap > 0 && !v.passthrough)
+        k_test_corrupt_payload<<<1, 1, 0, s>>>(ws.vals[0], ws.vals[1], sort_geom);
     if (cap > 0 && use_runs) {
         ProfScope ps(pf, O3DR_K_CENTROID_RUNS, s);
         k_centroid_runs<<<dim3(nbx, F), kPtThreads, 0, s>>>(

@@ -930,3 +930,21 @@ def test_error_behaviour_of_the_c_abi(Q, frame_1249):
             L.check(lib.o3dr_accumulate_frames(h, disp.ctypes.data, 100, 1280, bgr.ctypes.data, 3840 * 720, 3840, 720, 1280,
                                                T.ctypes.data, 1, L.MEM_HOST))
         assert c.cloudBigSize() == (0, 0)
+        # the gather guards: a sorted payload pointing outside the cloud (what a bookkeeping error upstream would leave
+        # behind) must come back as O3DR_ERR_INTERNAL with an empty output, never as a GPU fault (include/o3dr.h, pose.cpp:620-635)
+        pts = random_cloud(50000, 9)
+        leaf = (C.c_float * 3)(0.05, 0.05, 0.05)
+        buf = np.zeros(len(pts), o3dr.POINT)
+        for runs in (False, True):  # points are sorted as points / (dense cloud, coarse leaf) as runs
+            if runs:
+                pts = np.repeat(pts[:5000], 10)
+                leaf = (C.c_float * 3)(5.0, 5.0, 5.0)
+            L.check(lib.o3dr_test_corrupt_next_gather(h))
+            n.value = 123
+            rc = lib.o3dr_voxel_grid(h, pts.ctypes.data, len(pts), leaf, 0, C.c_float(0.0), buf.ctypes.data, len(buf), C.byref(n),
+                                     C.byref(st), L.MEM_HOST)
+            assert rc == L.ERR_INTERNAL and n.value == 0, (runs, rc, n.value)
+            assert b"guard" in lib.o3dr_last_error()
+            rc = lib.o3dr_voxel_grid(h, pts.ctypes.data, len(pts), leaf, 0, C.c_float(0.0), buf.ctypes.data, len(buf), C.byref(n),
+                                     C.byref(st), L.MEM_HOST)
+            assert rc == L.OK and n.value > 0  # the hook was one-shot; the context is fine
