@@ -303,13 +303,14 @@ def main():
 
     # ---- PCIe-inclusive rate: one extra, untimed-in-`value` step with HOST (pageable numpy) inputs -----------------
     if world == 1 and not args.host_inputs and not args.no_pcie_step:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctx.cloudBigReset()
-        ctx.accumulateFrames(disp_h, bgr_h, poses_h)
-        ctx.finalize(device=dev)
-        torch.cuda.synchronize()
-        result["pcie_inclusive_frames_per_sec"] = round(F / (time.perf_counter() - t0), 2)
+        for k in range(2):  # (the first call allocates the context's staging buffers; the second one is timed)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.cloudBigReset()
+            ctx.accumulateFrames(disp_h, bgr_h, poses_h)
+            ctx.finalize(device=dev)
+            torch.cuda.synchronize()
+            result["pcie_inclusive_frames_per_sec"] = round(F / (time.perf_counter() - t0), 2)
 
     # ---- verification: the whole step of the headline config against the oracle, bit for bit -----------------------
     result["verified"] = None
