@@ -1,7 +1,8 @@
 // o3dr_kernels.hip — hand-written gfx950 kernels of the reconstruction hot path.
 //
 //   K1  k_reproject_count / k_reproject_emit   A1+A2: (u,v,disparity) -> Q -> SE(3) -> ordered cloud
-//   K2  k_voxel_geom / k_voxel_keys            A4 steps 1-5: PCL VoxelGrid geometry and linear index
+//       (batched A6: k_reproject_bbox_count, then k_reproject_emit also writes the voxel index and counts pass-0 digits)
+//   K2  k_voxel_geom / k_voxel_keys_*          A4 steps 1-5: PCL VoxelGrid geometry and linear index
 //       k_radix_hist / k_radix_scatter_lane    A4 step 6: stable LSD radix sort of (index, point id)
 //       k_run_heads / k_run_starts / k_centroid  A4 steps 7-8: runs -> ordered fp32 centroid
 //
@@ -15,7 +16,7 @@
 // The device code lives in kernels/*.inc, one file per subsystem, all included below into this one translation
 // unit (a kernel and the launcher that names it must share a TU unless device code is built relocatable):
 //   util         wave/workgroup scans and reductions, helpers of the sort and run records
-//   reproject    K1: count / emit / keypoint pass / in-place transform
+//   reproject    K1: count / bbox + count / emit (+ index, first histogram) / keypoint pass / in-place transform
 //   bookkeeping  slot initialisation, exclusive scans, bounding box of a cloud
 //   prepass      bilateral filter and variance gate on the disparity image
 //   voxel_index  PCL VoxelGrid geometry, linear indices (+ fused first histogram / run-head counts)
