@@ -137,7 +137,9 @@ static void dev_release(DevBuf& b)
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // (re)carve the per-batch workspace for `frames` clouds of at most `cap` points
-static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
+// need_pts: ws.pts holds frames*cap points (A1 + A2 output); grp_tmp: ws.pts holds the result slots of the grouped
+// whole-cloud voxel grid (one cloud, not in ws.pts itself)
+static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool grp_tmp = false)
 {
     if (cap < 1) cap = 1;
     const size_t elems = (size_t)frames * (size_t)(cap + 1);
@@ -164,7 +166,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_seg = off;   off += align256(E * 4);
         size_t o_keep = off;  off += align256(E * 4);
         size_t o_rs = off;    off += align256(E * 4);
-        size_t o_rl = off;    off += align256(E * 4);
+        size_t o_gc = off;    off += align256(((E > (size_t)kGroupMinSlots ? E : (size_t)kGroupMinSlots) / kGroupCells + 2) * 4);
         size_t o_tile = off;  off += align256(TE * 4);
         size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
@@ -178,6 +180,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         size_t o_geom = off;  off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_geomr = off; off += align256((size_t)F * sizeof(VoxelGeom));
         size_t o_nr = off;    off += align256((size_t)F * 4);
+        size_t o_ng = off;    off += align256((size_t)F * 4);
         size_t o_omm = off;   off += align256((E / 64 + 8 * (size_t)F + 64) * 6 * sizeof(float));
         size_t o_ommp = off;  off += align256((size_t)kBoxFoldBlocks * 6 * sizeof(float));
         CHK(dev_ensure(c, c->ws_block, off));
@@ -190,7 +193,8 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         w.seg_start = (uint32_t*)(base + o_seg);
         w.keep_idx = (uint32_t*)(base + o_keep);
         w.run_start = (uint32_t*)(base + o_rs);
-        w.run_len = (uint32_t*)(base + o_rl);
+        w.grp_cnt = (uint32_t*)(base + o_gc);
+        w.n_grp_out = (uint32_t*)(base + o_ng);
         w.geom_runs = (VoxelGeom*)(base + o_geomr);
         w.n_runs = (uint32_t*)(base + o_nr);
         w.out_mm = (float*)(base + o_omm);
@@ -215,8 +219,11 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts)
         c->ws_mm_floats = MM;
     }
     c->ws.mm_stride = (int64_t)mm_slots;
-    if (need_pts) {
-        const size_t pe = (size_t)frames * (size_t)cap;
+    c->ws.grp_slots = 0;
+    if (need_pts || grp_tmp) {
+        size_t pe = (size_t)frames * (size_t)cap;
+        if (grp_tmp && pe < (size_t)kGroupMinSlots) pe = (size_t)kGroupMinSlots;
+        if (grp_tmp) c->ws.grp_slots = (int64_t)pe;
         if (pe > c->ws_pts_elems) {
             CHK(dev_ensure(c, c->ws_pts_block, pe * sizeof(o3dr_point)));
             c->ws_pts_elems = pe;
@@ -798,7 +805,7 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
                         const float* gmin = nullptr, const float* gmax = nullptr, bool do_sor = false,
                         const float* box_dev = nullptr)
 {
-    CHK(ws_ensure(c, 1, n_in, false));
+    CHK(ws_ensure(c, 1, n_in, false, c->use_runs != 0));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
     int mm_used = 1;
     if (gmin && gmax)  // grid laid over a caller-supplied (global) box instead of this cloud's own

@@ -30,6 +30,14 @@ static_assert(kMaxRadix <= 2 * kSortThreads, "k_radix_scatter handles two digits
 constexpr int kPtThreads = 256;
 constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head kernels
 constexpr int kMinmaxBlocks = 1024;  // workgroups (= bounding-box slots) of the stand-alone min/max pass
+// whole-cloud voxel grids (the merge): records of the sort are runs of consecutive points inside one GROUP of
+// 2^kGroupBits consecutive voxel indices; one wave then sums a group, lane = voxel (k_centroid_groups)
+constexpr int kGroupBits = 6;
+constexpr int kGroupCells = 1 << kGroupBits;
+static_assert(kGroupCells == kWave, "one lane per voxel of a group");
+constexpr int kGroupWaves = 4;            // groups per workgroup of k_centroid_groups
+constexpr int kGroupMinRun = 8;           // grouped records are used when they average at least this many points
+constexpr int64_t kGroupMinSlots = 1 << 20;  // result slots (16 bytes each) a context always has for the grouped path
 
 // ---- per-frame voxel grid geometry (PCL VoxelGrid members), written by k_voxel_geom -----------
 struct VoxelGeom {
@@ -42,7 +50,8 @@ struct VoxelGeom {
     uint32_t passes;      // radix passes this frame's index needs (0 when overflow)
     uint32_t bpp;         // bits per pass
     uint32_t buf0;        // buffer the first pass reads (sorted records end in buffer (passes + buf0) & 1)
-    uint32_t val_bits;    // run-compressed sorts: payload = first point | (points - 1) << val_bits; 0: payload = record id
+    uint32_t grouped;     // 1: the records are runs of consecutive points of one voxel group (n = number of records, payload =
+                          // record id into Workspace::run_start); 0: the records are the points (payload = point id)
 };
 
 // ---- statistical outlier removal (A3b): search grid + threshold, written by k_sor_plan / k_sor_threshold ----
@@ -104,10 +113,12 @@ struct Workspace {
     o3dr_point* sor_pts = nullptr;      // cap      inliers
     uint32_t* sor_n = nullptr;          // 1        inlier count
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
-    uint32_t* run_start = nullptr; // frames*(cap+1)  first point of every run (run-compressed path)
-    uint32_t* run_len = nullptr;   // frames*(cap+1)  run lengths in sorted order -> exclusive prefix (min_points > 1)
+    uint32_t* run_start = nullptr; // frames*(cap+1)  first point of every group run (grouped path), + sentinel
+    uint32_t* grp_cnt = nullptr;   // grp_slots/64 + 2: output voxels per group -> exclusive prefix (grouped path, frames == 1)
+    int64_t grp_slots = 0;         // 16-byte result slots available in `pts` for the grouped path (0: pts not reserved)
     uint32_t* n_runs = nullptr;    // frames
-    VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of runs, records starting in buffer 1
+    uint32_t* n_grp_out = nullptr; // frames: output voxels of a grouped cloud
+    VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of group runs, records starting in buffer 1
     float* out_mm = nullptr;         // frames*ceil(cap/256)*4*6: bounding boxes of what k_centroid's waves appended
     float* out_mm_partial = nullptr; // kBoxFoldBlocks*6
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
@@ -173,7 +184,9 @@ struct VoxelArgs {
     int passthrough;  // dont_downsample: append the input unchanged
     int mm_used;      // bounding-box slots to fold per frame
     SortStats* stats; // optional device statistics
-    int use_runs;     // sort runs of consecutive equal indices instead of points (whole-cloud calls)
+    int use_runs;     // whole-cloud calls (frames == 1): sort runs of consecutive points of one voxel group instead of points
+                      // when they are long enough (decided on the device; 2: whenever the result slots allow it); needs
+                      // ws.grp_slots result slots in ws.pts, which must not be the input
     float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
     int keys_ready = 0;  // launch_reproject_fused ran: ws.geom, the indices in ws.keys[0] and the first histogram exist
     int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: poison one sorted payload before the gather (guard test)

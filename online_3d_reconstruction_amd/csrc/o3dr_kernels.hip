@@ -174,15 +174,17 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                                        v.z_offset, ws.geom);
     }
     uint32_t* n_keep = nullptr;
-    // run compression: whole-cloud calls only
-    const bool use_runs = v.use_runs && !v.passthrough;
-    // what the sort and the run/cell kernels count (runs or points)
+    // grouped records: whole-cloud calls only (one cloud; its result slots live in ws.pts)
+    const bool use_runs = v.use_runs && !v.passthrough && F == 1 && v.in != ws.pts;
+    const int64_t grp_slots = use_runs ? ws.grp_slots : 0;
+    const int64_t max_groups = grp_slots / kGroupCells;
+    // what the sort and the run/cell kernels count (group runs or points)
     const VoxelGeom* sort_geom = use_runs ? ws.geom_runs : ws.geom;
     if (!v.passthrough && cap > 0) {
         const dim3 grid(n_sort_tiles, F);
         if (!(v.keys_ready && !use_runs)) {
             ProfScope ps(pf, O3DR_K_KEYGEN, s);
-            if (use_runs)  // indices and, in the same read, how many runs of equal indices start in every tile
+            if (use_runs)  // voxel groups and, in the same read, how many group runs start in every tile
                 k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
                                                                        ws.keys[0], n_seg_tiles, ws.seg_cnt);
             else  // ... and the histogram of the first radix pass
@@ -190,7 +192,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                                                                  n_sort_tiles, ws.hist);
         }
         if (use_runs) {
-            // runs of consecutive equal indices -> (run key, run id) records in buffer 1
+            // runs of consecutive points of one voxel group -> (group, run id) records in buffer 1
             const dim3 rgrid(n_seg_tiles, F);
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -198,10 +200,10 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             }
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                // runs or points?  (decided per cloud on the device; use_runs == 2 forces runs)
-                k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs, v.use_runs > 1 ? 1 : 0);
+                // group runs or points?  (decided per cloud on the device; use_runs == 2: group runs whenever they fit)
+                k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs, v.use_runs > 1 ? 1 : 0, grp_slots);
                 k_run_starts<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
-                                                  ws.run_start, 0, ws.keys[1], ws.geom_runs);  // run keys -> buffer 1
+                                                  ws.run_start, 0, ws.keys[1], ws.geom_runs, kGroupBits);  // run keys -> buffer 1
             }
         }
         // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
@@ -220,7 +222,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             {
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
                 k_radix_scatter_lane<<<dim3(cdiv64(n_sort_tiles, kScatterTilesPerWg), F), kSortThreads, 0, s>>>(
-                    ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, sort_geom, pass, n_sort_tiles, ws.hist, ws.run_start);
+                    ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, sort_geom, pass, n_sort_tiles, ws.hist);
             }
         }
         const dim3 sgrid(n_seg_tiles, F);
@@ -235,20 +237,11 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
             k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
-                                              ws.seg_start, -1, nullptr, nullptr);
+                                              ws.seg_start, -1, nullptr, nullptr, 0);
         }
-        if (v.min_points > 1) {
+        if (v.min_points > 1) {  // (grouped clouds filter inside k_centroid_groups and drop out of these on the device)
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                if (use_runs) {
-                    // points per voxel from a prefix sum over the sorted runs' lengths (one pass + one scan instead of
-                    // walking every voxel's runs twice); clouds that sort points skip these on the device
-                    k_run_lengths<<<dim3(cdiv64(cap + 1, 256), F), 256, 0, s>>>(ws.vals[0], ws.vals[1], ws.run_start, cap,
-                                                                             ws.geom_runs, ws.run_len);
-                    launch_scan(s, ws.run_len, cap + 1, cap + 1, F, nullptr, nullptr, ws.scan_partial, ws.geom_runs, -1, 0);
-                    k_keep_count_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
-                                                           n_seg_tiles, ws.seg_cnt);
-                }
                 k_keep_count<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, sort_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt);
             }
             {
@@ -257,28 +250,46 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             }
             {
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
-                if (use_runs)
-                    k_keep_write_runs<<<sgrid, 256, 0, s>>>(ws.seg_start, ws.run_len, cap, ws.geom_runs, ws.n_vox, v.min_points,
-                                                           n_seg_tiles, ws.seg_cnt, ws.keep_idx);
                 k_keep_write<<<sgrid, 256, 0, s>>>(ws.seg_start, cap, sort_geom, ws.n_vox, v.min_points, n_seg_tiles, ws.seg_cnt,
                                                   ws.keep_idx);
             }
             n_keep = ws.n_out;
         }
     }
-    {
-        ProfScope ps(pf, O3DR_K_OTHER, s);
-        k_frame_offsets<<<1, 256, 0, s>>>(ws.geom, ws.n_vox, n_keep, F, v.passthrough, ws.n_out, ws.out_off, v.cc,
-                                          v.stats, sort_geom);
-    }
-    const int nbx = cdiv64(cap, kPtThreads);
     if (v.test_corrupt && cap > 0 && !v.passthrough)
         k_test_corrupt_payload<<<1, 1, 0, s>>>(ws.vals[0], ws.vals[1], sort_geom);
     if (cap > 0 && use_runs) {
+        // one wave per voxel group; the groups' output counts are only known afterwards
+        {
+            ProfScope ps(pf, O3DR_K_OTHER, s);
+            (void)hipMemsetAsync(ws.grp_cnt, 0, sizeof(uint32_t) * (size_t)(max_groups + 1), s);
+        }
+        {
+            ProfScope ps(pf, O3DR_K_CENTROID_RUNS, s);
+            int64_t nwg = cdiv64(max_groups < cap ? max_groups : cap, kGroupWaves);
+            if (nwg > 16384) nwg = 16384;
+            if (nwg < 1) nwg = 1;
+            k_centroid_groups<<<(int)nwg, kGroupWaves * kWave, 0, s>>>(
+                v.in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.seg_start, ws.run_start, ws.geom_runs, ws.geom, ws.n_vox,
+                v.z_offset, v.min_points, reinterpret_cast<uint4*>(ws.pts), grp_slots, ws.grp_cnt, v.cc);
+        }
+        {
+            ProfScope ps(pf, O3DR_K_OTHER, s);
+            launch_scan(s, ws.grp_cnt, max_groups + 1, max_groups + 1, 1, ws.n_grp_out, nullptr, ws.scan_partial);
+        }
+    }
+    {
+        ProfScope ps(pf, O3DR_K_OTHER, s);
+        k_frame_offsets<<<1, 256, 0, s>>>(ws.geom, ws.n_vox, n_keep, use_runs ? ws.n_grp_out : nullptr, F, v.passthrough,
+                                          ws.n_out, ws.out_off, v.cc, v.stats, sort_geom);
+    }
+    const int nbx = cdiv64(cap, kPtThreads);
+    if (cap > 0 && use_runs) {
         ProfScope ps(pf, O3DR_K_CENTROID_RUNS, s);
-        k_centroid_runs<<<dim3(nbx, F), kPtThreads, 0, s>>>(
-            v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, ws.run_start,
-            v.min_points > 1 ? ws.keep_idx : nullptr, ws.geom_runs, ws.geom, ws.n_out, ws.out_off, v.z_offset, v.out_base, v.cc);
+        int64_t nwg = cdiv64(cap, 256);
+        if (nwg > 8192) nwg = 8192;
+        k_group_compact<<<(int)nwg, 256, 0, s>>>(v.in, ws.geom_runs, ws.geom, ws.n_vox, ws.grp_cnt,
+                                                reinterpret_cast<const uint4*>(ws.pts), ws.out_off, v.z_offset, v.out_base);
     }
     if (cap > 0) {
         ProfScope ps(pf, O3DR_K_CENTROID, s);
@@ -367,7 +378,7 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
         k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
         launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
         k_radix_scatter_lane<<<dim3(cdiv64(n_sort_tiles, kScatterTilesPerWg), 1), kSortThreads, 0, s>>>(
-            ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, nullptr);
+            ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
     }
     k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
                                                      ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);
