@@ -170,6 +170,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool g
         size_t o_tile = off;  off += align256(TE * 4);
         size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
+        size_t o_hb = off;    off += align256(TG * 256);
         size_t o_part = off;  off += align256(((TS * kMaxRadix + TG + TE + E) / 4096 + 8 * (size_t)F + 16) * 4);
         size_t o_mm = off;    off += align256(MM * 4);
         size_t o_nv = off;    off += align256((size_t)F * 4);
@@ -202,6 +203,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool g
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
+        w.head_bits = (uint8_t*)(base + o_hb);
         w.scan_partial = (uint32_t*)(base + o_part);
         w.mm = (float*)(base + o_mm);
         w.n_valid = (uint32_t*)(base + o_nv);

@@ -32,9 +32,9 @@ constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head ker
 constexpr int kMinmaxBlocks = 1024;  // workgroups (= bounding-box slots) of the stand-alone min/max pass
 // whole-cloud voxel grids (the merge): records of the sort are runs of consecutive points inside one GROUP of
 // 2^kGroupBits consecutive voxel indices; one wave then sums a group, lane = voxel (k_centroid_groups)
-constexpr int kGroupBits = 6;
+constexpr int kGroupBits = 5;
 constexpr int kGroupCells = 1 << kGroupBits;
-static_assert(kGroupCells == kWave, "one lane per voxel of a group");
+static_assert(kGroupCells <= kWave, "one lane per voxel of a group");
 constexpr int kGroupWaves = 4;            // groups per workgroup of k_centroid_groups
 constexpr int kGroupMinRun = 8;           // grouped records are used when they average at least this many points
 constexpr int64_t kGroupMinSlots = 1 << 20;  // result slots (16 bytes each) a context always has for the grouped path
@@ -101,6 +101,7 @@ struct Workspace {
     uint32_t* tile_cnt = nullptr;  // frames*n_emit_tiles
     uint32_t* hist = nullptr;      // frames*kMaxRadix*n_sort_tiles
     uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
+    uint8_t* head_bits = nullptr;  // frames*n_seg_tiles*256: run-head flags, 4 records per byte (k_run_heads -> k_run_starts)
     uint32_t* scan_partial = nullptr;  // chunk sums of the multi-workgroup scan
     // statistical outlier removal (single-cloud path)
     SorGeom* sor_geom = nullptr;

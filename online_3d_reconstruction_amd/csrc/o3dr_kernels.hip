@@ -186,7 +186,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             ProfScope ps(pf, O3DR_K_KEYGEN, s);
             if (use_runs)  // voxel groups and, in the same read, how many group runs start in every tile
                 k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
-                                                                       ws.keys[0], n_seg_tiles, ws.seg_cnt);
+                                                                       ws.keys[0], n_seg_tiles, ws.seg_cnt, ws.head_bits);
             else  // ... and the histogram of the first radix pass
                 k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap, ws.keys[0],
                                                                  n_sort_tiles, ws.hist);
@@ -202,8 +202,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
                 // group runs or points?  (decided per cloud on the device; use_runs == 2: group runs whenever they fit)
                 k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs, v.use_runs > 1 ? 1 : 0, grp_slots);
-                k_run_starts<<<rgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
-                                                  ws.run_start, 0, ws.keys[1], ws.geom_runs, kGroupBits);  // run keys -> buffer 1
+                k_run_starts<<<dim3(cdiv64(n_seg_tiles, kStartWaves), F), kStartWaves * kWave, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
+                                                  ws.run_start, 0, ws.keys[1], ws.geom_runs, kGroupBits, ws.head_bits);  // run keys -> buffer 1
             }
         }
         // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
@@ -228,7 +228,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         const dim3 sgrid(n_seg_tiles, F);
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, -1);
+            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, -1, ws.head_bits);
         }
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -236,8 +236,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         }
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_starts<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
-                                              ws.seg_start, -1, nullptr, nullptr, 0);
+            k_run_starts<<<dim3(cdiv64(n_seg_tiles, kStartWaves), F), kStartWaves * kWave, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
+                                              ws.seg_start, -1, nullptr, nullptr, 0, ws.head_bits);
         }
         if (v.min_points > 1) {  // (grouped clouds filter inside k_centroid_groups and drop out of these on the device)
             {
