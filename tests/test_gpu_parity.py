@@ -511,6 +511,54 @@ def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     assert_points_equal(vg, orc.voxel_grid(pts, (0.02, 0.03, 0.04), 0)[0], f"voxel grid {env}")
 
 
+@pytest.mark.parametrize("env", [None, {"O3DR_RUNS": "2"}, {"O3DR_RUNS": "0"}])
+def test_grouped_whole_cloud_voxel_grids(orc, monkeypatch, env):
+    """whole-cloud voxel grids over concatenations of clouds that are already in voxel order (what cloud_big is): the
+    records of the sort are runs of points inside one group of consecutive voxels and a wave sums a group
+    (k_centroid_groups).  Shapes that matter there: runs longer than a 256-point step, groups with more than 64 runs
+    (several windows), one huge group, a 3-D and a 2.5-D (combined) grid, min_points filters - default decision,
+    forced (O3DR_RUNS=2) and switched off (O3DR_RUNS=0) must all give the oracle's bits."""
+    import online_3d_reconstruction_amd as o3dr
+    if env:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(5)
+    parts = []
+    for i in range(24):  # 24 "frames" over one patch, each already in the voxel order of a fine grid
+        pts = random_cloud(60000, 900 + i, extent=(1.2, 0.9, 0.04), origin=(1.0 + 0.1 * (i % 5), -2.0 + 0.07 * (i % 7), 0.5))
+        parts.append(orc.voxel_grid(pts, (0.01, 0.01, 0.01), 0)[0])
+    big = np.concatenate(parts)
+    dense = random_cloud(300000, 321, extent=(0.6, 0.5, 0.2))           # a few voxels with thousands of points each
+    dense_sorted = orc.voxel_grid(dense, (0.002, 0.002, 0.002), 0)[0]
+    with o3dr.Context(0) as c:
+        for leaf, minpts in [((0.05, 0.05, 0.05), 0), ((0.05, 0.05, 1000.0), 3), ((0.2, 0.2, 0.1), 2), ((7.0, 7.0, 7.0), 0)]:
+            got, st = c.voxelGrid(big, leaf, minpts, return_status=True)
+            ref, rst = orc.voxel_grid(big, leaf, minpts)
+            assert st == rst == 0
+            assert_points_equal(got, ref, f"grouped grid leaf={leaf} min={minpts} env={env}")
+        for leaf in [(0.1, 0.1, 0.1), (0.02, 0.5, 0.02)]:
+            got = c.voxelGrid(dense_sorted, leaf, 0)
+            assert_points_equal(got, orc.voxel_grid(dense_sorted, leaf, 0)[0], f"grouped dense leaf={leaf} env={env}")
+        # which path ran: the sort's records are group runs (far fewer than points) unless switched off
+        c.profileReset()
+        c.voxelGrid(big, (0.05, 0.05, 1000.0), 0)
+        stats = c.profileStatsAll()
+        points_in, records = stats[1], stats[4]
+        assert points_in == len(big)
+        if env == {"O3DR_RUNS": "0"}:
+            assert records == len(big)
+        else:
+            assert records * 8 <= len(big), (records, len(big))
+        for vs, minpts in [(0.05, 1), (0.25, 4)]:                       # the combined merge itself (z + 500 / - 500)
+            c.set_params(_params(voxel_size=vs, min_points_per_voxel=minpts))
+            got = c.downsamplePtCloud(big, True)
+            assert_points_equal(got, orc.downsample_pt_cloud(big, vs, True, minpts)[0], f"grouped merge vs={vs} env={env}")
+        # shuffled input: no runs to speak of, the device falls back to sorting points (or, forced, takes one-point runs)
+        shuffled = big[rng.permutation(len(big))[:200000]]
+        got = c.voxelGrid(shuffled, (0.05, 0.05, 1000.0), 0)
+        assert_points_equal(got, orc.voxel_grid(shuffled, (0.05, 0.05, 1000.0), 0)[0], f"grouped shuffled env={env}")
+
+
 # ---- empty frames inside a batch (round-1 abort: an all-invalid frame's histogram spilled into its neighbour's) ----
 @pytest.mark.parametrize("jump", [1, 15, 0])
 @pytest.mark.parametrize("empty", [(0,), (2,), (4,), (1, 2), (0, 1, 2, 3, 4)])
