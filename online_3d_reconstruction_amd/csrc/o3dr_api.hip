@@ -85,6 +85,13 @@ struct o3dr_ctx {
     // o3dr_cloud_big_bbox need no pass over the cloud; invalid after appends / transforms / exchanges
     float* cloud_box = nullptr;
     bool cloud_box_valid = false;
+    // cloud_big's group-run heads for the merge's grid, recorded by the frame calls while it grows (4 points per byte);
+    // valid under the same conditions as the running box, and for the leaf they were recorded with
+    uint32_t* cloud_heads = nullptr;
+    int64_t cloud_heads_cap = 0;  // points the flag buffer covers
+    bool cloud_heads_valid = false;
+    float cloud_heads_leaf[3] = {0.f, 0.f, 0.f};
+    float cloud_heads_zo = 0.f;
     int cloud_box_enable = 1;  // O3DR_NO_CLOUD_BOX=1: always take the bounding box with a pass over the cloud
     CloudCounters* cc_big = nullptr;   // device
     CloudCounters* cc_tmp = nullptr;   // device, for single-shot calls
@@ -184,6 +191,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool g
         size_t o_ng = off;    off += align256((size_t)F * 4);
         size_t o_omm = off;   off += align256((E / 64 + 8 * (size_t)F + 64) * 6 * sizeof(float));
         size_t o_ommp = off;  off += align256((size_t)kBoxFoldBlocks * 6 * sizeof(float));
+        size_t o_wgc = off;   off += align256((E / 64 + 8 * (size_t)F + 64) * 6 * sizeof(int32_t));
         CHK(dev_ensure(c, c->ws_block, off));
         char* base = (char*)c->ws_block.p;
         Workspace& w = c->ws;
@@ -200,6 +208,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool g
         w.n_runs = (uint32_t*)(base + o_nr);
         w.out_mm = (float*)(base + o_omm);
         w.out_mm_partial = (float*)(base + o_ommp);
+        w.wave_gc = (int32_t*)(base + o_wgc);
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
         w.seg_cnt = (uint32_t*)(base + o_segc);
@@ -364,6 +373,7 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->cloud_big) (void)hipFree(c->cloud_big);
     if (c->cloud_alt) (void)hipFree(c->cloud_alt);
     if (c->cloud_box) (void)hipFree(c->cloud_box);
+    if (c->cloud_heads) (void)hipFree(c->cloud_heads);
     if (c->cc_big) (void)hipFree(c->cc_big);
     if (c->cc_tmp) (void)hipFree(c->cc_tmp);
     if (c->cc_host) (void)hipHostFree(c->cc_host);
@@ -805,7 +815,7 @@ static int put_bbox(o3dr_ctx* c, const float mn[3], const float mx[3])
 static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const float leaf[3], uint32_t min_points,
                         float z_offset, o3dr_point* out_d, int64_t* n_out, uint32_t* status,
                         const float* gmin = nullptr, const float* gmax = nullptr, bool do_sor = false,
-                        const float* box_dev = nullptr)
+                        const float* box_dev = nullptr, const uint8_t* heads_in = nullptr)
 {
     CHK(ws_ensure(c, 1, n_in, false, c->use_runs != 0));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
@@ -834,6 +844,7 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     v.mm_used = mm_used;
     v.stats = c->stats_dev;
     v.use_runs = c->use_runs;
+    v.heads_in = heads_in;
     v.test_corrupt = c->test_corrupt;
     c->test_corrupt = 0;
     if (do_sor) {
@@ -980,6 +991,24 @@ static int cloud_reserve(o3dr_ctx* c, int64_t need)
     }
     c->cloud_big = nb;
     c->cloud_cap = want;
+    // the flag buffer follows the cloud's capacity (zeros where nothing was recorded yet)
+    if (c->cloud_box_enable) {
+        const size_t bytes = ((size_t)want / 4 + 64 + 3) & ~(size_t)3;
+        uint32_t* nf = nullptr;
+        if (hipMalloc((void**)&nf, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(O3DR_ERR_ALLOC, "hipMalloc failed (cloud_big run heads)");
+        }
+        HIPCHK(hipMemsetAsync(nf, 0, bytes, c->stream));
+        if (c->cloud_heads) {
+            const size_t old = ((size_t)c->cloud_heads_cap / 4 + 64 + 3) & ~(size_t)3;
+            HIPCHK(hipMemcpyAsync(nf, c->cloud_heads, old < bytes ? old : bytes, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(c->cloud_heads));
+        }
+        c->cloud_heads = nf;
+        c->cloud_heads_cap = want;
+    }
     return O3DR_OK;
 }
 
@@ -1035,7 +1064,39 @@ static int cloud_box_clear(o3dr_ctx* c)
                                    -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     HIPCHK(hipMemcpyAsync(c->cloud_box, empty, sizeof empty, hipMemcpyHostToDevice, c->stream));
     c->cloud_box_valid = c->cloud_box_enable != 0;
+    if (c->cloud_heads) HIPCHK(hipMemsetAsync(c->cloud_heads, 0, ((size_t)c->cloud_heads_cap / 4 + 64 + 3) & ~(size_t)3, c->stream));
+    c->cloud_heads_valid = c->cloud_box_enable != 0;
     return O3DR_OK;
+}
+
+// frame calls that append to cloud_big also record where its group runs start, for the merge's grid
+static void heads_for_append(o3dr_ctx* c, VoxelArgs& v)
+{
+    if (!c->cloud_heads_valid || !c->cloud_heads) return;
+    float leaf[3], zo;
+    uint32_t mp;
+    downsample_leaf(c->params, 1, leaf, &mp, &zo);
+    const bool same = leaf[0] == c->cloud_heads_leaf[0] && leaf[1] == c->cloud_heads_leaf[1] && leaf[2] == c->cloud_heads_leaf[2] &&
+                      zo == c->cloud_heads_zo;
+    if (c->cloud_ub == 0) {  // an empty cloud takes the current leaf
+        for (int a = 0; a < 3; ++a) c->cloud_heads_leaf[a] = leaf[a];
+        c->cloud_heads_zo = zo;
+    } else if (!same) {  // voxel_size changed while the cloud was growing: the flags describe no single grid
+        c->cloud_heads_valid = false;
+        return;
+    }
+    v.cloud_heads.flags = c->cloud_heads;
+    for (int a = 0; a < 3; ++a) v.cloud_heads.inv[a] = 1.0f / leaf[a];
+    v.cloud_heads.z_offset = zo;
+}
+// ... and the merge takes them instead of reading the cloud once more
+static const uint8_t* heads_for_merge(o3dr_ctx* c, const float leaf[3], float zo)
+{
+    if (!c->cloud_heads_valid || !c->cloud_heads) return nullptr;
+    if (leaf[0] != c->cloud_heads_leaf[0] || leaf[1] != c->cloud_heads_leaf[1] || leaf[2] != c->cloud_heads_leaf[2] ||
+        zo != c->cloud_heads_zo)
+        return nullptr;
+    return reinterpret_cast<const uint8_t*>(c->cloud_heads);
 }
 
 extern "C" int o3dr_cloud_big_reset(o3dr_ctx* c)
@@ -1103,6 +1164,7 @@ extern "C" int o3dr_cloud_big_append(o3dr_ctx* c, const o3dr_point* pts, int64_t
     v.mm_used = 0;
     v.stats = nullptr;
     c->cloud_box_valid = false;  // appended points are not tracked
+    c->cloud_heads_valid = false;
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     c->cloud_ub += n;
@@ -1119,6 +1181,7 @@ extern "C" int o3dr_cloud_big_transform(o3dr_ctx* c, const float T[16])
     launch_transform(&c->prof, c->stream, c->cloud_big, (int64_t)cc.count, T, c->cloud_big);
     HIPCHK(hipGetLastError());
     c->cloud_box_valid = false;
+    c->cloud_heads_valid = false;
     return O3DR_OK;
 }
 
@@ -1197,6 +1260,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
             v.stats = c->stats_dev;
             v.use_runs = 0;
             v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
+            heads_for_append(c, v);
             v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap,
                                    (int)((g.n + kEmitTile - 1) / kEmitTile) + 1, 1.0, c->ws.sor_pts, c->ws.sor_n);
             launch_voxel_grid(&c->prof, c->stream, c->ws, v);
@@ -1272,6 +1336,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         VoxelArgs v;
         v.keys_ready = fused ? 1 : 0;
         v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
+        heads_for_append(c, v);
         v.in = c->ws.pts;
         v.in_fstride = cap;
         v.n_dev = c->ws.n_valid;
@@ -1345,7 +1410,7 @@ static int finalize_impl(o3dr_ctx* c, const float* gmin, const float* gmax, o3dr
     int64_t m = 0;
     uint32_t st = 0;
     CHK(voxel_single(c, c->cloud_big, n, leaf, mp, zo, out_d, &m, &st, gmin, gmax, false,
-                     c->cloud_box_valid ? c->cloud_box : nullptr));
+                     c->cloud_box_valid ? c->cloud_box : nullptr, heads_for_merge(c, leaf, zo)));
     if (mem == O3DR_MEM_HOST) {
         if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
         if (m > 0) {
@@ -1412,6 +1477,7 @@ extern "C" int o3dr_cloud_big_adopt(o3dr_ctx* c, int64_t n_points)
     HIPCHK(hipStreamSynchronize(c->stream));
     swap_clouds(c);
     c->cloud_box_valid = false;
+    c->cloud_heads_valid = false;
     c->cloud_ub = n_points;
     return O3DR_OK;
 }
@@ -1483,6 +1549,7 @@ extern "C" int o3dr_cloud_big_partition(o3dr_ctx* c, const float gmin[3], const 
     HIPCHK(hipMemcpyAsync(c->misc_host, c->misc_dev, 64 + 8 * (size_t)n_parts, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     swap_clouds(c);  // the partitioned copy becomes cloud_big; the old buffer is kept as the alternate
+    c->cloud_heads_valid = false;
     const uint32_t ovf = *(const uint32_t*)(c->misc_host + 32);
     const uint64_t* hc = (const uint64_t*)(c->misc_host + 64);
     for (int p = 0; p < n_parts; ++p) counts[p] = (int64_t)hc[p];

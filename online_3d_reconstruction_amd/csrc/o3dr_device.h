@@ -122,6 +122,7 @@ struct Workspace {
     VoxelGeom* geom_runs = nullptr;  // frames: geom with n = number of group runs, records starting in buffer 1
     float* out_mm = nullptr;         // frames*ceil(cap/256)*4*6: bounding boxes of what k_centroid's waves appended
     float* out_mm_partial = nullptr; // kBoxFoldBlocks*6
+    int32_t* wave_gc = nullptr;      // frames*ceil(cap/256)*4*6: voxel groups of the first / last point k_centroid's waves appended
     float* mm = nullptr;           // frames*mm_stride*6  per-workgroup bounding boxes (min xyz, max xyz)
     int64_t mm_stride = 0;         // slots per frame
     uint32_t* n_valid = nullptr;   // frames     points per frame after A1
@@ -141,6 +142,15 @@ struct SortStats {
     uint64_t reserved;
     uint64_t sort_records;        // records entering the sorts (points, or runs of points)
     uint64_t pad[3];
+};
+
+// where cloud_big records the heads of its group runs while it is appended to (k_centroid): the flags (4 records per
+// byte, see k_run_heads) and the merge grid they are meant for
+struct CloudHeads {
+    uint32_t* flags;  // nullptr: not recorded
+    float inv[3];     // inverse leaf of the merge's grid
+    float z_offset;
+    int32_t* wave_gc; // workspace: groups of the first and the last point every wave of k_centroid appended (6 ints per wave)
 };
 
 // device-resident counters of the accumulating cloud
@@ -189,6 +199,8 @@ struct VoxelArgs {
                       // when they are long enough (decided on the device; 2: whenever the result slots allow it); needs
                       // ws.grp_slots result slots in ws.pts, which must not be the input
     float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
+    CloudHeads cloud_heads = {nullptr, {0.f, 0.f, 0.f}, 0.f, nullptr};  // appending to cloud_big: record the group-run heads of what is appended
+    const uint8_t* heads_in = nullptr;  // whole-cloud call on a cloud whose group-run heads are recorded already (for this leaf)
     int keys_ready = 0;  // launch_reproject_fused ran: ws.geom, the indices in ws.keys[0] and the first histogram exist
     int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: poison one sorted payload before the gather (guard test)
 };

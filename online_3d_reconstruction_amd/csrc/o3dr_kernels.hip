@@ -182,18 +182,17 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     const VoxelGeom* sort_geom = use_runs ? ws.geom_runs : ws.geom;
     if (!v.passthrough && cap > 0) {
         const dim3 grid(n_sort_tiles, F);
-        if (!(v.keys_ready && !use_runs)) {
-            ProfScope ps(pf, O3DR_K_KEYGEN, s);
-            if (use_runs)  // voxel groups and, in the same read, how many group runs start in every tile
-                k_voxel_keys_heads<<<dim3(n_seg_tiles, F), 256, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap,
-                                                                       ws.keys[0], n_seg_tiles, ws.seg_cnt, ws.head_bits);
-            else  // ... and the histogram of the first radix pass
-                k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap, ws.keys[0],
-                                                                 n_sort_tiles, ws.hist);
-        }
         if (use_runs) {
-            // runs of consecutive points of one voxel group -> (group, run id) records in buffer 1
-            const dim3 rgrid(n_seg_tiles, F);
+            // the heads of the group runs (runs of consecutive points of one voxel group) per segment tile: recorded
+            // while the cloud was appended to, or from one read of the points
+            const uint8_t* hb = v.heads_in ? v.heads_in : ws.head_bits;
+            {
+                ProfScope ps(pf, O3DR_K_KEYGEN, s);
+                if (v.heads_in)
+                    k_head_counts<<<cdiv64(n_seg_tiles, 4), 256, 0, s>>>(v.heads_in, ws.geom, n_seg_tiles, ws.seg_cnt);
+                else
+                    k_group_heads<<<n_seg_tiles, 256, 0, s>>>(v.in, ws.geom, v.z_offset, n_seg_tiles, ws.seg_cnt, ws.head_bits);
+            }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
                 launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_runs, nullptr, ws.scan_partial);
@@ -202,9 +201,20 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 ProfScope ps(pf, O3DR_K_SEGMENT, s);
                 // group runs or points?  (decided per cloud on the device; use_runs == 2: group runs whenever they fit)
                 k_run_geom<<<cdiv64(F, 64), 64, 0, s>>>(ws.geom, ws.n_runs, F, ws.geom_runs, v.use_runs > 1 ? 1 : 0, grp_slots);
-                k_run_starts<<<dim3(cdiv64(n_seg_tiles, kStartWaves), F), kStartWaves * kWave, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs,
-                                                  ws.run_start, 0, ws.keys[1], ws.geom_runs, kGroupBits, ws.head_bits);  // run keys -> buffer 1
+                // (group, run id) records in buffer 1
+                k_run_starts<<<dim3(cdiv64(n_seg_tiles, kStartWaves), F), kStartWaves * kWave, 0, s>>>(
+                    ws.keys[0], ws.keys[1], cap, ws.geom, n_seg_tiles, ws.seg_cnt, ws.n_runs, ws.run_start, 0, ws.keys[1],
+                    ws.geom_runs, v.in, v.z_offset, hb);
             }
+            {
+                ProfScope ps(pf, O3DR_K_KEYGEN, s);  // a cloud left to the point sort needs PCL's index per point after all
+                k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap, ws.keys[0],
+                                                                 n_sort_tiles, ws.hist, ws.geom_runs);
+            }
+        } else if (!v.keys_ready) {  // PCL's index per point and the histogram of the first radix pass
+            ProfScope ps(pf, O3DR_K_KEYGEN, s);
+            k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap, ws.keys[0],
+                                                             n_sort_tiles, ws.hist, nullptr);
         }
         // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
         const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
@@ -237,7 +247,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
             k_run_starts<<<dim3(cdiv64(n_seg_tiles, kStartWaves), F), kStartWaves * kWave, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
-                                              ws.seg_start, -1, nullptr, nullptr, 0, ws.head_bits);
+                                              ws.seg_start, -1, nullptr, nullptr, nullptr, 0.f, ws.head_bits);
         }
         if (v.min_points > 1) {  // (grouped clouds filter inside k_centroid_groups and drop out of these on the device)
             {
@@ -294,15 +304,21 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     if (cap > 0) {
         ProfScope ps(pf, O3DR_K_CENTROID, s);
         float* out_mm = v.cloud_box ? ws.out_mm : nullptr;
+        CloudHeads heads = v.cloud_heads;
+        heads.wave_gc = ws.wave_gc;
         const uint32_t* keep = (v.min_points > 1 && !v.passthrough) ? ws.keep_idx : nullptr;
         if (use_runs)  // only for clouds k_run_geom left to the point sort: a small looping grid
             k_centroid<true><<<dim3(nbx < 4096 ? nbx : 4096, F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom_runs, ws.n_out, ws.out_off,
-                v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc);
+                v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc, CloudHeads{nullptr, {0.f, 0.f, 0.f}, 0.f, nullptr});
         else
             k_centroid<false><<<dim3(nbx, F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom, ws.n_out, ws.out_off,
-                v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc);
+                v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc, heads);
+        if (!use_runs && v.cloud_heads.flags) {  // the first point of every wave against the last one of the wave before it
+            const int wpf = nbx * (kPtThreads / 64);
+            k_cloud_heads_fix<<<dim3(cdiv64(wpf, 256), F), 256, 0, s>>>(ws.n_out, ws.out_off, wpf, heads);
+        }
     }
     if (v.cloud_box && cap > 0 && !use_runs) {
         ProfScope ps(pf, O3DR_K_OTHER, s);
