@@ -37,6 +37,7 @@ constexpr int kGroupCells = 1 << kGroupBits;
 static_assert(kGroupCells <= kWave, "one lane per voxel of a group");
 constexpr int kGroupWaves = 4;            // groups per workgroup of k_centroid_groups
 constexpr int kGroupMinRun = 8;           // grouped records are used when they average at least this many points
+constexpr int64_t kGroupMinCloud = 1 << 20;  // whole-cloud calls on fewer points sort the points
 constexpr int64_t kGroupMinSlots = 1 << 20;  // result slots (16 bytes each) a context always has for the grouped path
 
 // ---- per-frame voxel grid geometry (PCL VoxelGrid members), written by k_voxel_geom -----------

@@ -175,7 +175,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     }
     uint32_t* n_keep = nullptr;
     // grouped records: whole-cloud calls only (one cloud; its result slots live in ws.pts)
-    const bool use_runs = v.use_runs && !v.passthrough && F == 1 && v.in != ws.pts;
+    // (below ~a million points the extra launches cost more than the point sort saves; use_runs == 2 still forces it)
+    const bool use_runs = v.use_runs && !v.passthrough && F == 1 && v.in != ws.pts && (v.use_runs > 1 || cap >= kGroupMinCloud);
     const int64_t grp_slots = use_runs ? ws.grp_slots : 0;
     const int64_t max_groups = grp_slots / kGroupCells;
     // what the sort and the run/cell kernels count (group runs or points)

@@ -524,7 +524,7 @@ def test_grouped_whole_cloud_voxel_grids(orc, monkeypatch, env):
             monkeypatch.setenv(k, v)
     rng = np.random.default_rng(5)
     parts = []
-    for i in range(24):  # 24 "frames" over one patch, each already in the voxel order of a fine grid
+    for i in range(36):  # 36 "frames" over one patch (> kGroupMinCloud points in all), each already in the voxel order of a fine grid
         pts = random_cloud(60000, 900 + i, extent=(1.2, 0.9, 0.04), origin=(1.0 + 0.1 * (i % 5), -2.0 + 0.07 * (i % 7), 0.5))
         parts.append(orc.voxel_grid(pts, (0.01, 0.01, 0.01), 0)[0])
     big = np.concatenate(parts)
