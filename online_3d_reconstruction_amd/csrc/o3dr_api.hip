@@ -530,6 +530,10 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
                  : 0;
     memcpy(a.Q, c->Q, sizeof a.Q);
     a.min_disp = c->params.min_disparity;
+    {   // the same comparison on integers (no fp64 convert + compare per pixel): d > m <=> d > floor(m) for integer d
+        const double m = a.min_disp;
+        a.min_disp_u8 = !(m == m) || m >= 255.0 ? 255 : (m < 0.0 ? -1 : (int32_t)floor(m));
+    }
     a.out_fstride = out_fstride;
     a.mm_stride = c->ws.mm_stride;
     a.lut = (c->q_lut_on && !a.disp_f64) ? c->q_lut : nullptr;

@@ -84,6 +84,7 @@ struct ReprojectArgs {
     int32_t vec4;         // 1: jump==1, Nx%4==0, cs%4==0, pitches%4==0 -> packed 4-pixel loads
     double Q[16];
     double min_disp;
+    int32_t min_disp_u8;  // for disparity BYTES: d > min_disp  <=>  (int)d > min_disp_u8 (set next to min_disp)
     int64_t out_fstride;  // points between consecutive frames' output regions
     int64_t mm_stride;    // bounding-box slots per frame
     const QLutEntry* lut; // 256 entries in HBM when Q has the rectified-stereo sparsity, else nullptr
