@@ -234,12 +234,12 @@ def main():
     bytes_per_step = {
         "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate
         "reproject_emit": 4 * n_cand * F + 16 * nv,            # 1 B disparity + 3 B colour in, 16 B point out
-        "voxel_keys": 20 * (nv + merge_in),                    # 16 B point in, 4 B index out
+        "voxel_keys": 0.25 * merge_in,                         # batch path: indices come from the emit pass; the merge reads its run-head flags
         "radix_hist": 4 * rec_passes,                          # 4 B index per record per pass
         "radix_scatter": 16 * rec_passes - 4 * sort_recs,      # (index,id) in and out; pass 0 has no id to read
-        "run_segments": 8 * (nv + merge_in) + 4 * vox_out,     # index read twice, run starts written
+        "run_segments": 4.5 * sort_recs + 4 * vox_out,         # index read once, head flags out and in, run starts written
         "centroid": 20 * nv + 16 * m1,                         # id + gathered point in, centroid out
-        "centroid_runs": 16 * merge_n + 16 * m2,               # merge: points in (runs are contiguous), cells out
+        "centroid_runs": 16 * merge_n + 16 * m2,               # merge: points in (group runs are contiguous), cells out
     }
     dom_name = L.KERNEL_NAMES[dom]
     achieved = bytes_per_step[dom_name] * args.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

@@ -268,7 +268,7 @@ int o3dr_cloud_big_adopt(o3dr_ctx* ctx, int64_t n_points);
 #define O3DR_K_SEGMENT      5  /* voxel run heads + counts */
 #define O3DR_K_CENTROID     6  /* ordered per-voxel sums -> centroid */
 #define O3DR_K_OTHER        7  /* scans, grid setup, copies */
-#define O3DR_K_CENTROID_RUNS 8 /* ordered per-voxel sums over runs of points (whole-cloud calls) */
+#define O3DR_K_CENTROID_RUNS 8 /* ordered per-voxel sums over group runs of points, one wave per voxel group (whole-cloud calls) */
 #define O3DR_K_NUM          9
 /* Bracket every launch of kernel `kernel_id` (or all kernels if -1) with HIP events on the
  * context's stream; 0 launches are bracketed when disabled (the default). */
