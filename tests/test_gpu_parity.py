@@ -905,6 +905,53 @@ def test_running_bounding_box_of_cloud_big(ctx, orc):
     assert_points_equal(ctx.finalize(), orc.downsample_pt_cloud(big3, 0.05, True, 1)[0], "merge after reset")
 
 
+def test_cloud_big_keeps_its_group_run_heads(ctx, orc):
+    """cloud_big records where its group runs start while frame calls append to it (k_centroid / k_cloud_heads_fix), and
+    the merge starts from those flags instead of reading the cloud once more.  Several accumulate calls, a reset, a
+    voxel_size that changes while the cloud grows, foreign appends and transforms: the merge must equal the oracle's every
+    time, on the grouped path (dense frames: > 1 M points)"""
+    from online_3d_reconstruction_amd import synth
+    Qs = synth.camera_Q()
+    ctx.set_camera(Qs)
+    disp, bgr = synth.make_frames(700, 6, invalid_frac=0.01)
+    poses = synth.make_poses(700, 6)
+
+    def merged_equals_oracle(what, vs, grouped=True):
+        big = ctx.cloudBigRead()
+        assert len(big) > (1 << 20)
+        ctx.profileReset()
+        got = ctx.finalize()
+        stats = ctx.profileStatsAll()
+        assert_points_equal(got, orc.downsample_pt_cloud(big, vs, True, 1)[0], what)
+        assert stats[1] == len(big)
+        if grouped:
+            assert stats[4] * 8 <= len(big), (what, stats[4], len(big))  # the sort's records were group runs
+        return big
+
+    ctx.set_params(_params(jump_pixels=1, voxel_size=0.05))
+    ctx.cloudBigReset()
+    ctx.accumulateFrames(disp[:2], bgr[:2], poses[:2])
+    ctx.accumulateFrames(disp[2:3], bgr[2:3], poses[2:3])            # a second call appends behind the first
+    merged_equals_oracle("recorded heads, two calls", 0.05)
+    ctx.accumulateFrames(disp[3:4], bgr[3:4], poses[3:4])            # ... and the cloud keeps growing after a merge
+    merged_equals_oracle("recorded heads, grown after a merge", 0.05)
+    ctx.cloudBigTransform(_pose(4))                                  # coordinates changed: the flags are dropped
+    merged_equals_oracle("after a transform", 0.05, grouped=False)       # (rotated rows: the device may prefer the point sort)
+    ctx.cloudBigReset()
+    ctx.accumulateFrames(disp[:3], bgr[:3], poses[:3])
+    ctx.cloudBigAppend(random_cloud(7000, 5, extent=(30.0, 30.0, 2.0)))  # foreign points: dropped as well
+    merged_equals_oracle("after a foreign append", 0.05)
+    ctx.cloudBigReset()
+    ctx.accumulateFrames(disp[:2], bgr[:2], poses[:2])
+    ctx.set_params(_params(jump_pixels=1, voxel_size=0.08))          # another grid while the cloud grows
+    ctx.accumulateFrames(disp[2:5], bgr[2:5], poses[2:5])
+    merged_equals_oracle("voxel_size changed between calls", 0.08)
+    ctx.cloudBigReset()
+    ctx.accumulateFrames(disp[1:6], bgr[1:6], poses[1:6])            # a reset starts over, with the new grid
+    merged_equals_oracle("after a reset", 0.08)
+    ctx.set_params(_params(jump_pixels=1, voxel_size=0.05))
+
+
 def test_A7_dont_downsample_accumulates_raw_points(ctx, orc):
     """--dont_downsample (pose.cpp:609, 534-537): cloud_big is the concatenation of the transformed frames and the
     final cloud is cloud_big itself; the tracked bounding box covers the passthrough path too"""
