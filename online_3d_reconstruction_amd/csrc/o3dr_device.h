@@ -27,6 +27,7 @@ constexpr int kMaxRadix = 1 << kMaxRadixBits;
 constexpr int kMaxPasses = 5;            // 5 x 7 bits covers a full 32-bit index
 static_assert(kMaxRadix <= 2 * kSortThreads, "k_radix_scatter handles two digits per thread");
 // generic per-point kernels
+constexpr int kXcds = 8;   // accelerator complex dies of an MI355X, each with its own L2 (xcd_chunk_item)
 constexpr int kPtThreads = 256;
 constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head kernels
 constexpr int kMinmaxBlocks = 1024;  // workgroups (= bounding-box slots) of the stand-alone min/max pass

@@ -110,6 +110,7 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     }
 }
 
+static inline int xcd_grid(int64_t n) { return (int)((n + kXcds - 1) / kXcds * kXcds); }  // see xcd_chunk_item
 void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, int frames, int64_t cap,
                             const float leaf[3])
 {
@@ -232,7 +233,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             }
             {
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
-                k_radix_scatter_lane<<<dim3(cdiv64(n_sort_tiles, kScatterTilesPerWg), F), kSortThreads, 0, s>>>(
+                k_radix_scatter_lane<<<dim3(xcd_grid(cdiv64(n_sort_tiles, kScatterTilesPerWg)), F), kSortThreads, 0, s>>>(
                     ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, sort_geom, pass, n_sort_tiles, ws.hist);
             }
         }
@@ -313,7 +314,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom_runs, ws.n_out, ws.out_off,
                 v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc, CloudHeads{nullptr, {0.f, 0.f, 0.f}, 0.f, nullptr});
         else
-            k_centroid<false><<<dim3(nbx, F), kPtThreads, 0, s>>>(
+            k_centroid<false><<<dim3(xcd_grid(nbx), F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom, ws.n_out, ws.out_off,
                 v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc, heads);
         if (!use_runs && v.cloud_heads.flags) {  // the first point of every wave against the last one of the wave before it
@@ -394,7 +395,7 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     for (int pass = 0; pass < kMaxPasses; ++pass) {
         k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
         launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
-        k_radix_scatter_lane<<<dim3(cdiv64(n_sort_tiles, kScatterTilesPerWg), 1), kSortThreads, 0, s>>>(
+        k_radix_scatter_lane<<<dim3(xcd_grid(cdiv64(n_sort_tiles, kScatterTilesPerWg)), 1), kSortThreads, 0, s>>>(
             ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
     }
     k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
