@@ -65,6 +65,7 @@ struct o3dr_ctx {
     double bil_sc = 0, bil_ss = 0;
     bool bil_valid = false;
     int max_batch = 256;  // frames per launch group (O3DR_BATCH_FRAMES); also bounded by a workspace budget
+    int slab_shift_env = -2;  // O3DR_SLABS=0: plain pixel order in the fused batch path; O3DR_SLABS=sN: slabs of 2^N cells; else automatic
     int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs; 2: always runs
 
     Workspace ws;
@@ -344,6 +345,9 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;       // whole-cloud grids always sort points
     else if (ru_env && atoi(ru_env) == 2) c->use_runs = 2;  // ... always sort runs (default: decided per cloud on the device)
     if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
+    const char* sl_env = getenv("O3DR_SLABS");
+    if (sl_env && sl_env[0] == '0') c->slab_shift_env = -1;
+    else if (sl_env && sl_env[0] == 's' && atoi(sl_env + 1) >= 0 && atoi(sl_env + 1) <= 20) c->slab_shift_env = atoi(sl_env + 1);
     const char* env = getenv("O3DR_BATCH_FRAMES");
     if (env && atoi(env) > 0) c->max_batch = atoi(env) > 512 ? 512 : atoi(env);
     (void)cloud_box_clear(c);
@@ -537,6 +541,32 @@ static void fill_args(o3dr_ctx* c, ReprojectArgs& a, const uint8_t* disp, int64_
     a.out_fstride = out_fstride;
     a.mm_stride = c->ws.mm_stride;
     a.lut = (c->q_lut_on && !a.disp_f64) ? c->q_lut : nullptr;
+}
+
+// Thickness (log2, in cells) of the grid slabs the fused batch path sorts a frame's points into (slab_class in
+// kernels/reproject.inc): about two thirds of the distance between the depth sheets of two neighbouring disparity levels
+// at a nominal disparity, so that the sheets one line of pixels lands on fall into different classes.  A layout choice
+// only: results do not depend on it.  -1: plain pixel order (O3DR_SLABS=0).
+static int slab_shift_for(const o3dr_ctx* c, int rows, int cols, const float leaf[3])
+{
+    if (c->slab_shift_env >= -1) return c->slab_shift_env;
+    const double* Q = c->Q;
+    auto point = [&](double d, double out[3]) {
+        const double v[4] = {0.5 * cols, 0.5 * rows, d, 1.0};
+        double t[4];
+        for (int r = 0; r < 4; ++r) t[r] = ((Q[4 * r] * v[0] + Q[4 * r + 1] * v[1]) + Q[4 * r + 2] * v[2]) + Q[4 * r + 3];
+        for (int r = 0; r < 3; ++r) out[r] = t[r] / t[3];
+    };
+    double p0[3], p1[3];
+    point(128.0, p0);
+    point(129.0, p1);
+    const double dist = sqrt((p1[0] - p0[0]) * (p1[0] - p0[0]) + (p1[1] - p0[1]) * (p1[1] - p0[1]) + (p1[2] - p0[2]) * (p1[2] - p0[2]));
+    const double lf = leaf[0] > leaf[1] ? (leaf[0] > leaf[2] ? leaf[0] : leaf[2]) : (leaf[1] > leaf[2] ? leaf[1] : leaf[2]);
+    const double cells = dist / lf / 1.5;
+    if (!(cells >= 2.0)) return 0;  // (also NaN / inf from a degenerate Q)
+    int sh = 0;
+    while (sh < 16 && (double)(2 << sh) <= cells) ++sh;
+    return sh;
 }
 
 // stage a host buffer into HBM (or pass a device pointer through)
@@ -1326,6 +1356,8 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
                   bgr_frame_stride, rows, cols, g, cap);
         a.xf_mode = 2;
         a.poses = (const float*)poses_d;
+        for (int i = 0; i < 3; ++i) a.slab_inv[i] = 1.0f / leaf[i];
+        a.slab_shift = slab_shift_for(c, rows, cols, leaf);
         launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
         // no keypoint pass in front of the grid pass and a voxel grid behind it: index and first digit histogram are
         // produced by the pass that writes the points (the keypoint pass would need them too: it keeps the two-step form)

@@ -27,6 +27,7 @@ constexpr int kMaxRadix = 1 << kMaxRadixBits;
 constexpr int kMaxPasses = 5;            // 5 x 7 bits covers a full 32-bit index
 static_assert(kMaxRadix <= 2 * kSortThreads, "k_radix_scatter handles two digits per thread");
 // generic per-point kernels
+constexpr int kSlabClasses = 4;  // layout classes inside an emit tile of the fused batch path (slab_class)
 constexpr int kXcds = 8;   // accelerator complex dies of an MI355X, each with its own L2 (xcd_chunk_item)
 constexpr int kPtThreads = 256;
 constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head kernels
@@ -90,6 +91,9 @@ struct ReprojectArgs {
     int64_t mm_stride;    // bounding-box slots per frame
     const QLutEntry* lut; // 256 entries in HBM when Q has the rectified-stereo sparsity, else nullptr
     int32_t disp_f64;     // disparity image holds doubles (CV_64F, --use_segment_labels) instead of bytes
+    // fused batch path only: the points of an emit tile are written class by class (grid slabs, see slab_class)
+    float slab_inv[3];    // inverse leaf of the grid the points are meant for
+    int32_t slab_shift;   // log2 of the slab thickness in cells; < 0: one class, plain pixel order
 };
 
 // All per-batch device buffers.  Sizes are for `frames` frames of at most `cap` points each.
@@ -173,8 +177,8 @@ void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, c
 void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int frames, o3dr_point* out,
                       uint32_t* tile_cnt, const uint32_t* n_kp, uint32_t* n_valid, float* mm,
                       uint32_t* scan_partial);
-// A1 + A2 of a batch with the per-frame grid's index and first digit histogram produced in the same pass over the
-// pixels (bounding boxes and counts first, then PCL's geometry, then the points): for launch_voxel_grid with
+// A1 + A2 of a batch with the per-frame grid's index produced in the same pass over the pixels as the points
+// (bounding boxes and counts first, then PCL's geometry, then the points): for launch_voxel_grid with
 // v.keys_ready = 1.  No keypoint pass (n_kp must hold zeros).
 void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, int frames, int64_t cap,
                             const float leaf[3]);
@@ -204,7 +208,7 @@ struct VoxelArgs {
     float* cloud_box = nullptr;  // device, 6 floats: running bounding box of out_base's cloud, extended by this call
     CloudHeads cloud_heads = {nullptr, {0.f, 0.f, 0.f}, 0.f, nullptr};  // appending to cloud_big: record the group-run heads of what is appended
     const uint8_t* heads_in = nullptr;  // whole-cloud call on a cloud whose group-run heads are recorded already (for this leaf)
-    int keys_ready = 0;  // launch_reproject_fused ran: ws.geom, the indices in ws.keys[0] and the first histogram exist
+    int keys_ready = 0;  // launch_reproject_fused ran: ws.geom and the indices in ws.keys[0] exist
     int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: poison one sorted payload before the gather (guard test)
 };
 constexpr int kBoxFoldBlocks = 1024;  // workgroups (and partial boxes) of the running-bounding-box fold

@@ -104,9 +104,9 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
         if (a.disp_f64)
-            k_reproject_emit<true, false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr, 0, nullptr, 0, nullptr);
+            k_reproject_emit<true, false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr, 0, nullptr);
         else
-            k_reproject_emit<false, false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr, 0, nullptr, 0, nullptr);
+            k_reproject_emit<false, false><<<grid, kEmitThreads, 0, s>>>(a, out, tile_cnt, n_kp, mm, nullptr, 0, nullptr);
     }
 }
 
@@ -115,7 +115,6 @@ void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const Re
                             const float leaf[3])
 {
     const dim3 grid(a.n_tiles, frames);
-    const int n_sort_tiles = cdiv64(cap, kSortTile);
     {
         ProfScope ps(pf, O3DR_K_COUNT, s);
         if (a.disp_f64)
@@ -127,16 +126,13 @@ void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const Re
         ProfScope ps(pf, O3DR_K_OTHER, s);
         launch_scan(s, ws.tile_cnt, a.n_tiles, a.n_tiles, frames, ws.n_valid, ws.n_kp, ws.scan_partial);
         k_voxel_geom<<<frames, 256, 0, s>>>(ws.mm, ws.mm_stride, a.n_tiles + 1, ws.n_valid, leaf[0], leaf[1], leaf[2], 0.f, ws.geom);
-        (void)hipMemsetAsync(ws.hist, 0, sizeof(uint32_t) * (size_t)frames * kMaxRadix * n_sort_tiles, s);
     }
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
         if (a.disp_f64)
-            k_reproject_emit<true, true><<<grid, kEmitThreads, 0, s>>>(a, ws.pts, ws.tile_cnt, ws.n_kp, ws.mm, ws.geom, cap, ws.keys[0],
-                                                                      n_sort_tiles, ws.hist);
+            k_reproject_emit<true, true><<<grid, kEmitThreads, 0, s>>>(a, ws.pts, ws.tile_cnt, ws.n_kp, ws.mm, ws.geom, cap, ws.keys[0]);
         else
-            k_reproject_emit<false, true><<<grid, kEmitThreads, 0, s>>>(a, ws.pts, ws.tile_cnt, ws.n_kp, ws.mm, ws.geom, cap, ws.keys[0],
-                                                                       n_sort_tiles, ws.hist);
+            k_reproject_emit<false, true><<<grid, kEmitThreads, 0, s>>>(a, ws.pts, ws.tile_cnt, ws.n_kp, ws.mm, ws.geom, cap, ws.keys[0]);
     }
 }
 
@@ -221,7 +217,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
         const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
         for (int pass = 0; pass < kMaxPasses; ++pass) {
-            if (!(pass == 0 && !use_runs)) {
+            if (!(pass == 0 && !use_runs && !v.keys_ready)) {  // (k_voxel_keys_hist0 counted the first pass's digits)
                 ProfScope ps(pf, O3DR_K_SORT_HIST, s);
                 k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, pass, n_sort_tiles,
                                                           ws.hist);

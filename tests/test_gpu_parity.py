@@ -511,6 +511,37 @@ def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     assert_points_equal(vg, orc.voxel_grid(pts, (0.02, 0.03, 0.04), 0)[0], f"voxel grid {env}")
 
 
+@pytest.mark.parametrize("slabs", [None, "0", "s0", "s2", "s7"])
+def test_slab_layout_of_the_fused_batch_path_stays_bit_exact(orc, monkeypatch, slabs):
+    """the fused batch path writes the points of an emit tile layout class by layout class (grid slabs along the world
+    axis closest to the optical axis, kernels/reproject.inc slab_class) so that the per-voxel sums find the points of a
+    line together; whatever the slab thickness (automatic, off, 1 / 4 / 128 cells) the order of the points inside every
+    voxel - hence every bit of every centroid - stays the oracle's.  Cases: the per-frame leaf below and far above the
+    spacing of the depth sheets, cameras looking along world z / x / y, invalid pixels, a frame without a valid pixel,
+    and a leaf that trips PCL's overflow guard (output = input, in pixel order)."""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    if slabs is not None:
+        monkeypatch.setenv("O3DR_SLABS", slabs)
+    Qs = synth.camera_Q()
+    F = 4
+    disp, bgr = synth.make_frames(31, F, invalid_frac=0.03)
+    disp[2] = 0                                        # an accepted frame without a single valid pixel
+    poses = synth.make_poses(31, F)
+    rx = np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32)   # optical axis -> world y
+    ry = np.array([[0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 0, 1]], np.float32)   # optical axis -> world x
+    poses[1] = (rx @ poses[1]).astype(np.float32)
+    poses[3] = (ry @ poses[3]).astype(np.float32)
+    for vs, minpts in [(0.05, 1), (2.0, 2), (0.0004, 1)]:
+        with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=1, voxel_size=vs, min_points_per_voxel=minpts)) as c:
+            c.accumulateFrames(disp, bgr, poses)
+            big = c.cloudBigRead()
+            small = c.finalize()
+        rbig, rsmall, _ = _oracle_run(orc, Qs, disp, bgr, poses, vs, 1, minpts)
+        assert_points_equal(big, rbig, f"cloud_big vs={vs} slabs={slabs}")
+        assert_points_equal(small, rsmall, f"cloud_small vs={vs} slabs={slabs}")
+
+
 @pytest.mark.parametrize("env", [None, {"O3DR_RUNS": "2"}, {"O3DR_RUNS": "0"}])
 def test_grouped_whole_cloud_voxel_grids(orc, monkeypatch, env):
     """whole-cloud voxel grids over concatenations of clouds that are already in voxel order (what cloud_big is): the
