@@ -226,7 +226,7 @@ def main():
     m1_total, m2 = state["m1_total"], state["m2"]
 
     # ---- algorithmic bytes per step (DESIGN.md "Kernels and rooflines") --------------------------------
-    rec_passes, vox_in, vox_out, _unused, sort_recs, pk_recs, pk_passes = (v / args.steps for v in stats[:7])  # device counters, per step
+    rec_passes, vox_in, vox_out, _unused, sort_recs = (v / args.steps for v in stats[:5])  # device counters, per step
     nv = n_valid_total  # valid points of this rank's frames (per step)
     merge_n = m1_total // world  # points entering the combined merge on this rank (its index slice)
     m1 = m1_total // world       # per-frame voxels of this rank's frames
@@ -235,11 +235,8 @@ def main():
         "reproject_count": 1 * n_cand * F,                     # 1 B disparity per candidate
         "reproject_emit": 4 * n_cand * F + 16 * nv,            # 1 B disparity + 3 B colour in, 16 B point out
         "voxel_keys": 0.25 * merge_in,                         # batch path: indices come from the emit pass; the merge reads its run-head flags
-        # 4 B index per record per pass; 48-bit records: 4 + 6 + 2 + 2 B over the four 7-bit passes of a 28-bit index
-        "radix_hist": 4 * (rec_passes - pk_passes) + 3.5 * pk_passes,
-        # (index,id) in and out, pass 0 has no id to read: 16 P - 4 bytes per record of a P-pass sort; as 48-bit records
-        # (4 in, 6 out) + (6 in, 6 out) x (P - 2) + (6 in, 8 out) = 12 P
-        "radix_scatter": 16 * rec_passes - 4 * sort_recs - (4 * pk_passes - 4 * pk_recs),
+        "radix_hist": 4 * rec_passes,                          # 4 B index per record per pass
+        "radix_scatter": 16 * rec_passes - 4 * sort_recs,      # (index,id) in and out; pass 0 has no id to read
         "run_segments": 4.5 * sort_recs + 4 * vox_out,         # index read once, head flags out and in, run starts written
         "centroid": 20 * nv + 16 * m1,                         # id + gathered point in, centroid out
         "centroid_runs": 16 * merge_n + 16 * m2,               # merge: points in (group runs are contiguous), cells out
@@ -301,8 +298,7 @@ def main():
         "end_to_end": {"algorithmic_GBps": round(e2e_gbs, 2), "frac_of_hbm_peak": round(e2e_gbs / HBM_PEAK_GBS / world, 5),
                        "bytes_per_frame": int(b_frame), "bytes_final_merge": int(b_final)},
         "kernel_ms_per_step": {k: round(v[0], 3) for k, v in per_kernel.items()},
-        "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes),
-                 "records_48bit_per_step": int(pk_recs), "record_passes_48bit_per_step": int(pk_passes)},
+        "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes)},
     }
 
     # ---- PCIe-inclusive rate: one extra, untimed-in-`value` step with HOST (pageable numpy) inputs -----------------

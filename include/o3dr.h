@@ -279,8 +279,7 @@ int o3dr_profile_reset(o3dr_ctx* ctx);
 /* Synchronises; counters since the last o3dr_profile_reset, for algorithmic-byte accounting:
  * out[0] = sum over voxel grids of (records x radix passes actually run), out[1] = points that entered
  * voxel grids, out[2] = points that left them, out[3] = 0, out[4] = records that entered the sorts (points or runs
- * of points), out[5] = those of them sorted as 48-bit records (a 720p frame's per-frame grid: index below 2^28, at most
- * 2^20 points; 6 bytes per record between the passes instead of 8), out[6] = their record-passes, out[7] = 0. */
+ * of points), out[5..7] = 0. */
 int o3dr_profile_stats(o3dr_ctx* ctx, int64_t out[8]);
 /* Test hook for the gather guards: the next o3dr_voxel_grid / o3dr_downsample_pt_cloud / o3dr_finalize of this
  * context finds one of its sorted payloads pointing outside the cloud, as a bookkeeping error upstream would leave it.

@@ -1701,9 +1701,7 @@ extern "C" int o3dr_profile_stats(o3dr_ctx* c, int64_t out[8])
     out[2] = (int64_t)c->stats_host->voxel_points_out;
     out[3] = 0;
     out[4] = (int64_t)c->stats_host->sort_records;
-    out[5] = (int64_t)c->stats_host->packed_records;
-    out[6] = (int64_t)c->stats_host->packed_record_passes;
-    out[7] = 0;
+    out[5] = out[6] = out[7] = 0;
     return O3DR_OK;
 }
 extern "C" int o3dr_device_info(o3dr_ctx* c, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes)

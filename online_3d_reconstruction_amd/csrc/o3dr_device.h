@@ -24,7 +24,6 @@ constexpr int kMaxRadixBits = 7;           // digits are 1..7 bits wide, chosen 
                                           // the ballot scatter: 7-bit passes 3.8 TB/s, 10-bit ones 2.5 TB/s (32-byte
                                           // output runs); the lane-counting scatter keeps 128 x 17 counters per wave
 constexpr int kMaxRadix = 1 << kMaxRadixBits;
-constexpr int kPackIdBits = 20, kPackKeyBits = 28, kPackSplit = kPackKeyBits - 16;  // 48-bit sort records (VoxelGeom::packed)
 constexpr int kMaxPasses = 5;            // 5 x 7 bits covers a full 32-bit index
 static_assert(kMaxRadix <= 2 * kSortThreads, "k_radix_scatter handles two digits per thread");
 // generic per-point kernels
@@ -56,8 +55,6 @@ struct VoxelGeom {
     uint32_t buf0;        // buffer the first pass reads (sorted records end in buffer (passes + buf0) & 1)
     uint32_t grouped;     // 1: the records are runs of consecutive points of one voxel group (n = number of records, payload =
                           // record id into Workspace::run_start); 0: the records are the points (payload = point id)
-    uint32_t packed;      // 1: between the sort passes a record travels as 48 bits instead of 64 (radix_sort.inc: index
-                          // below 2^kPackKeyBits and at most 2^kPackIdBits records); the last pass writes plain (index, id)
 };
 
 // ---- statistical outlier removal (A3b): search grid + threshold, written by k_sor_plan / k_sor_threshold ----
@@ -151,9 +148,7 @@ struct SortStats {
     uint64_t voxel_points_out;    // points leaving them
     uint64_t reserved;
     uint64_t sort_records;        // records entering the sorts (points, or runs of points)
-    uint64_t packed_records;      // ... of which sorted as 48-bit records (VoxelGeom::packed)
-    uint64_t packed_record_passes;
-    uint64_t pad[1];
+    uint64_t pad[3];
 };
 
 // where cloud_big records the heads of its group runs while it is appended to (k_centroid): the flags (4 records per

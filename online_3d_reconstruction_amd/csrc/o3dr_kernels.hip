@@ -125,7 +125,7 @@ void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const Re
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         launch_scan(s, ws.tile_cnt, a.n_tiles, a.n_tiles, frames, ws.n_valid, ws.n_kp, ws.scan_partial);
-        k_voxel_geom<<<frames, 256, 0, s>>>(ws.mm, ws.mm_stride, a.n_tiles + 1, ws.n_valid, leaf[0], leaf[1], leaf[2], 0.f, ws.geom, 1);
+        k_voxel_geom<<<frames, 256, 0, s>>>(ws.mm, ws.mm_stride, a.n_tiles + 1, ws.n_valid, leaf[0], leaf[1], leaf[2], 0.f, ws.geom);
     }
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);
@@ -168,7 +168,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     if (!v.keys_ready) {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         k_voxel_geom<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, v.mm_used, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2],
-                                       v.z_offset, ws.geom, v.use_runs ? 0 : 1);
+                                       v.z_offset, ws.geom);
     }
     uint32_t* n_keep = nullptr;
     // grouped records: whole-cloud calls only (one cloud; its result slots live in ws.pts)
@@ -219,8 +219,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         for (int pass = 0; pass < kMaxPasses; ++pass) {
             if (!(pass == 0 && !use_runs && !v.keys_ready)) {  // (k_voxel_keys_hist0 counted the first pass's digits)
                 ProfScope ps(pf, O3DR_K_SORT_HIST, s);
-                k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], cap, sort_geom, pass,
-                                                          n_sort_tiles, ws.hist);
+                k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, pass, n_sort_tiles,
+                                                          ws.hist);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
@@ -365,7 +365,7 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
     const int n_sort_tiles = cdiv64(cap, kSortTile);
     const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
     ProfScope ps(pf, O3DR_K_OTHER, s);
-    k_voxel_geom<<<1, 256, 0, s>>>(ws.mm, ws.mm_stride, 1, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset, ws.geom, 0);
+    k_voxel_geom<<<1, 256, 0, s>>>(ws.mm, ws.mm_stride, 1, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset, ws.geom);
     // count per (part, tile), scan, move the points (two reads and one write of the cloud); n_parts <= kMaxRadix
     k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
     k_part_count<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist);
@@ -389,8 +389,7 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     (void)hipMemsetAsync(ws.sor_cell_end, 0, (size_t)ws.sor_max_cells * 4, s);
     k_sor_cells<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.sor_geom, ws.keys[0]);
     for (int pass = 0; pass < kMaxPasses; ++pass) {
-        k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], cap, ws.geom, pass,
-                                                                   n_sort_tiles, ws.hist);
+        k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
         launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
         k_radix_scatter_lane<<<dim3(xcd_grid(cdiv64(n_sort_tiles, kScatterTilesPerWg)), 1), kSortThreads, 0, s>>>(
             ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist);
