@@ -177,6 +177,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool g
         size_t o_gc = off;    off += align256(((E > (size_t)kGroupMinSlots ? E : (size_t)kGroupMinSlots) / kGroupCells + 2) * 4);
         size_t o_tile = off;  off += align256(TE * 4);
         size_t o_hist = off;  off += align256(TS * kMaxRadix * 4);
+        size_t o_histp = off; off += align256(TS * kMaxRadix * 4);
         size_t o_segc = off;  off += align256(TG * 4);
         size_t o_hb = off;    off += align256(TG * 256);
         size_t o_part = off;  off += align256(((TS * kMaxRadix + TG + TE + E) / 4096 + 8 * (size_t)F + 16) * 4);
@@ -212,6 +213,7 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool g
         w.wave_gc = (int32_t*)(base + o_wgc);
         w.tile_cnt = (uint32_t*)(base + o_tile);
         w.hist = (uint32_t*)(base + o_hist);
+        w.hist_part = (uint32_t*)(base + o_histp);
         w.seg_cnt = (uint32_t*)(base + o_segc);
         w.head_bits = (uint8_t*)(base + o_hb);
         w.scan_partial = (uint32_t*)(base + o_part);

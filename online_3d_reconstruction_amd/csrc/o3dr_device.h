@@ -20,6 +20,12 @@ constexpr int kSortThreads = kSortWaves * kWave;
 constexpr int kSortRounds = 16;
 constexpr int kSortWaveItems = kSortRounds * kWave;
 constexpr int kSortTile = kSortWaves * kSortWaveItems;
+// the scatter takes a tile in kScatParts parts, one workgroup of kScatWaves waves each (k_radix_scatter_lane): more and
+// smaller workgroups per CU overlap their LDS phases better; the histograms keep the 8192-record tile
+constexpr int kScatParts = 2;
+constexpr int kScatWaves = kSortWaves / kScatParts;
+constexpr int kScatThreads = kScatWaves * kWave;
+constexpr int kScatTile = kScatWaves * kSortWaveItems;
 constexpr int kMaxRadixBits = 7;           // digits are 1..7 bits wide, chosen per frame (k_voxel_geom).  Measured with
                                           // the ballot scatter: 7-bit passes 3.8 TB/s, 10-bit ones 2.5 TB/s (32-byte
                                           // output runs); the lane-counting scatter keeps 128 x 17 counters per wave
@@ -107,6 +113,7 @@ struct Workspace {
     uint32_t* seg_start = nullptr; // frames*(cap+1)   start of each voxel run in the sorted order
     uint32_t* tile_cnt = nullptr;  // frames*n_emit_tiles
     uint32_t* hist = nullptr;      // frames*kMaxRadix*n_sort_tiles
+    uint32_t* hist_part = nullptr; // frames*kMaxRadix*n_sort_tiles: digit counts of the FIRST scatter part of every tile
     uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
     uint8_t* head_bits = nullptr;  // frames*n_seg_tiles*256: run-head flags, 4 records per byte (k_run_heads -> k_run_starts)
     uint32_t* scan_partial = nullptr;  // chunk sums of the multi-workgroup scan
