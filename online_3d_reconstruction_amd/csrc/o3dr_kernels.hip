@@ -174,8 +174,6 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     // grouped records: whole-cloud calls only (one cloud; its result slots live in ws.pts)
     // (below ~a million points the extra launches cost more than the point sort saves; use_runs == 2 still forces it)
     const bool use_runs = v.use_runs && !v.passthrough && F == 1 && v.in != ws.pts && (v.use_runs > 1 || cap >= kGroupMinCloud);
-    // every run kept and the records are points: the sums walk the sorted records (k_centroid_rec) instead of the voxels
-    const bool by_record = !use_runs && !v.passthrough && v.min_points <= 1 && cap > 0;
     const int64_t grp_slots = use_runs ? ws.grp_slots : 0;
     const int64_t max_groups = grp_slots / kGroupCells;
     // what the sort and the run/cell kernels count (group runs or points)
@@ -244,7 +242,7 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             ProfScope ps(pf, O3DR_K_OTHER, s);
             launch_scan(s, ws.seg_cnt, n_seg_tiles, n_seg_tiles, F, ws.n_vox, nullptr, ws.scan_partial);
         }
-        if (!by_record) {  // (k_centroid_rec works from the head flags and the tiles' offsets)
+        {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
             k_run_starts<<<dim3(cdiv64(n_seg_tiles, kStartWaves), F), kStartWaves * kWave, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, ws.n_vox,
                                               ws.seg_start, -1, nullptr, nullptr, nullptr, 0.f, ws.head_bits);
@@ -311,32 +309,19 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             k_centroid<true><<<dim3(nbx < 4096 ? nbx : 4096, F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom_runs, ws.n_out, ws.out_off,
                 v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc, CloudHeads{nullptr, {0.f, 0.f, 0.f}, 0.f, nullptr});
-        else if (by_record)
-            k_centroid_rec<<<dim3(xcd_grid(n_seg_tiles), F), kRecWaves * kWave, 0, s>>>(
-                v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.head_bits, ws.seg_cnt, n_seg_tiles, ws.geom, ws.out_off,
-                v.z_offset, v.out_base, out_mm, ws.wave_gc, v.cc, heads);
         else
             k_centroid<false><<<dim3(xcd_grid(nbx), F), kPtThreads, 0, s>>>(
                 v.in, v.in_fstride, ws.vals[0], ws.vals[1], cap, ws.seg_start, keep, ws.geom, ws.n_out, ws.out_off,
                 v.z_offset, v.passthrough, v.out_base, out_mm, nbx, v.cc, heads);
         if (!use_runs && v.cloud_heads.flags) {  // the first point of every wave against the last one of the wave before it
-            if (by_record) {
-                const int wpf = n_seg_tiles * kRecWaves;
-                k_cloud_heads_fix_rec<<<dim3(cdiv64(wpf, 256), F), 256, 0, s>>>(ws.geom, ws.out_off, wpf, ws.wave_gc, heads);
-            } else {
-                const int wpf = nbx * (kPtThreads / 64);
-                k_cloud_heads_fix<<<dim3(cdiv64(wpf, 256), F), 256, 0, s>>>(ws.n_out, ws.out_off, wpf, heads);
-            }
+            const int wpf = nbx * (kPtThreads / 64);
+            k_cloud_heads_fix<<<dim3(cdiv64(wpf, 256), F), 256, 0, s>>>(ws.n_out, ws.out_off, wpf, heads);
         }
     }
     if (v.cloud_box && cap > 0 && !use_runs) {
         ProfScope ps(pf, O3DR_K_OTHER, s);
-        if (by_record) {
-            k_cloud_bbox_fold_rec<<<kBoxFoldBlocks, 256, 0, s>>>(ws.out_mm, n_seg_tiles * kRecWaves, F, ws.geom, ws.out_mm_partial);
-        } else {
-            const int nbx = cdiv64(cap, kPtThreads) * (kPtThreads / 64);
-            k_cloud_bbox_fold<<<kBoxFoldBlocks, 256, 0, s>>>(ws.out_mm, nbx, F, ws.n_out, ws.out_mm_partial);
-        }
+        const int nbx = cdiv64(cap, kPtThreads) * (kPtThreads / 64);
+        k_cloud_bbox_fold<<<kBoxFoldBlocks, 256, 0, s>>>(ws.out_mm, nbx, F, ws.n_out, ws.out_mm_partial);
         k_cloud_bbox_merge<<<1, 384, 0, s>>>(ws.out_mm_partial, kBoxFoldBlocks, v.cloud_box);
     }
 }
