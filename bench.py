@@ -100,6 +100,8 @@ def main():
                     help="hand the library HOST buffers (frames cross PCIe inside the timed region); reported as "
                          "metric frames_per_sec_pcie_inclusive, never the headline value")
     ap.add_argument("--pinned", action="store_true", help="with --host-inputs: page-locked host buffers")
+    ap.add_argument("--verify-max-frames", type=int, default=2000, help="N > 1: rank 0 re-creates the frames of all ranks and "
+                    "checks the merged cloud against the oracle when there are at most this many in all")
     ap.add_argument("--cpu-frames", type=int, default=200)
     ap.add_argument("--cpu-threads", type=int, default=7)
     ap.add_argument("--gen-workers", type=int, default=min(16, os.cpu_count() or 1))
@@ -184,6 +186,7 @@ def main():
             out = ctx.finalize(device=dev)
         state["m1_total"] = m1
         state["m2"] = int(out.shape[0])
+        state["out"] = out
         return out
 
     def barrier():
@@ -333,6 +336,26 @@ def main():
                                   "oracle_merged_points": int(len(rsmall)), "merged_bit_equal": bool(ok_small),
                                   "oracle_seconds": round(t_or, 2)}
         del big, rbig
+
+    # ---- N > 1: the merged cloud every rank holds after the exchange against the oracle's run over ALL ranks' frames ---
+    if rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1 and F * world <= args.verify_max_frames:
+        from oracle import orc
+        all_disp, all_bgr = generate_frames(0, F * world, args.rows, args.cols, args.invalid_frac, args.gen_workers)
+        all_poses = synth.make_poses(0, F * world)
+        t0 = time.perf_counter()
+        rbig, rsmall = orc.run_frames(all_disp, all_bgr, Q, all_poses, args.voxel_size, jump_pixels=args.jump_pixels,
+                                      min_points_per_voxel=args.min_points, sor=args.sor, threads=args.cpu_threads)
+        t_or = time.perf_counter() - t0
+        small = o3dr.api.points_from_torch(state["out"])
+        ok_big = int(m1_total) == len(rbig)
+        ok_small = len(small) == len(rsmall) and np.array_equal(small.view(np.uint32), rsmall.view(np.uint32))
+        result["verified"] = bool(ok_big and ok_small)
+        result["verification"] = {"against": "oracle/o3dr_oracle.c (orc_run_frames) on the frames and poses of all ranks",
+                                  "cloud_big_points_all_ranks": int(m1_total), "oracle_cloud_big_points": int(len(rbig)),
+                                  "cloud_big_count_equal": bool(ok_big), "merged_points": int(len(small)),
+                                  "oracle_merged_points": int(len(rsmall)), "merged_bit_equal": bool(ok_small),
+                                  "oracle_seconds": round(t_or, 2)}
+        del rbig, all_disp, all_bgr
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
         nf = min(args.cpu_frames, F)
