@@ -20,7 +20,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def load(d, counter):
     out = collections.defaultdict(list)
-    for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+    # (gpurun merges every call's files into gpurun_out/: only the newest collection counts)
+    for path in sorted(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("o3dr::k_", "").split("<")[0]

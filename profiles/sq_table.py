@@ -4,6 +4,7 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 
@@ -11,7 +12,8 @@ def main():
     d = sys.argv[1]
     want = sys.argv[2:]
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+    # (gpurun merges every call's files into gpurun_out/: only the newest collection counts)
+    for path in sorted(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(path)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("o3dr::", "")
             if want and not any(w in name for w in want):
