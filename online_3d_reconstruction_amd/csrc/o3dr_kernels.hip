@@ -236,7 +236,8 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
         const dim3 sgrid(n_seg_tiles, F);
         {
             ProfScope ps(pf, O3DR_K_SEGMENT, s);
-            k_run_heads<<<sgrid, 256, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles, ws.seg_cnt, -1, ws.head_bits);
+            k_run_heads<<<dim3(cdiv64(n_seg_tiles, kHeadWaves), F), kHeadWaves * kWave, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, n_seg_tiles,
+                                                                                       ws.seg_cnt, -1, ws.head_bits);
         }
         {
             ProfScope ps(pf, O3DR_K_OTHER, s);
