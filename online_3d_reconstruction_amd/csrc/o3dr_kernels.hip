@@ -118,9 +118,9 @@ void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const Re
     {
         ProfScope ps(pf, O3DR_K_COUNT, s);
         if (a.disp_f64)
-            k_reproject_bbox_count<true><<<grid, kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
+            k_reproject_bbox_count<true><<<dim3(cdiv64(a.n_tiles, kCountTiles), frames), kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
         else
-            k_reproject_bbox_count<false><<<grid, kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
+            k_reproject_bbox_count<false><<<dim3(cdiv64(a.n_tiles, kCountTiles), frames), kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
     }
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
