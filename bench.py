@@ -338,7 +338,19 @@ def main():
         del big, rbig
 
     # ---- N > 1: the merged cloud every rank holds after the exchange against the oracle's run over ALL ranks' frames ---
-    if rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1 and F * world <= args.verify_max_frames:
+    def host_can_verify(total_frames):
+        # the oracle holds all ranks' cloud_big twice and its sort records: ~3.5 x 16 bytes per candidate point
+        try:
+            import psutil
+            need = 3.5 * 16 * n_cand * total_frames + 4.0 * args.rows * args.cols * total_frames
+            return psutil.virtual_memory().available > 1.25 * need
+        except Exception:
+            return total_frames <= 400
+
+    if rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1 and not (
+            F * world <= args.verify_max_frames and host_can_verify(F * world)):
+        result["verification"] = {"skipped": f"{F * world} frames in all: above --verify-max-frames or the host's free memory"}
+    elif rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
         from oracle import orc
         all_disp, all_bgr = generate_frames(0, F * world, args.rows, args.cols, args.invalid_frac, args.gen_workers)
         all_poses = synth.make_poses(0, F * world)
