@@ -511,6 +511,38 @@ def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     assert_points_equal(vg, orc.voxel_grid(pts, (0.02, 0.03, 0.04), 0)[0], f"voxel grid {env}")
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 16385, 20481])
+def test_voxel_grid_sizes_around_the_tile_edges(ctx, orc, n):
+    """cloud sizes at and next to the edges of the kernels' work units: a scatter workgroup takes half (4096) of an
+    8192-record histogram tile, the run-head kernels take 1024 records per wave, a wave 64 outputs"""
+    pts = random_cloud(n, 1000 + n, extent=(0.9, 0.7, 0.4))
+    for leaf, minpts in [((0.05, 0.05, 0.05), 0), ((0.011, 0.013, 0.017), 0), ((0.2, 0.2, 0.2), 3)]:
+        got, st = ctx.voxelGrid(pts, leaf, minpts, return_status=True)
+        ref, rst = orc.voxel_grid(pts, leaf, minpts)
+        assert st == rst
+        assert_points_equal(got, ref, f"n={n} leaf={leaf} minpts={minpts}")
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 96), (72, 200), (131, 517)])
+def test_A7_small_images_in_a_batch(orc, rows, cols):
+    """frames of one to a few reprojection tiles through the batched path (the bounding-box pass takes four tiles per
+    workgroup, the emit pass orders a tile's points by slab class): odd sizes, no 4-pixel alignment"""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    Qs = synth.camera_Q(rows, cols)
+    F = 5
+    disp, bgr = synth.make_frames(3, F, rows=rows, cols=cols, invalid_frac=0.05)
+    poses = synth.make_poses(3, F)
+    for jump in (1, 2):
+        with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=jump, voxel_size=0.05, min_points_per_voxel=1)) as c:
+            c.accumulateFrames(disp, bgr, poses)
+            big = c.cloudBigRead()
+            small = c.finalize()
+        rbig, rsmall, _ = _oracle_run(orc, Qs, disp, bgr, poses, 0.05, jump, 1)
+        assert_points_equal(big, rbig, f"cloud_big {rows}x{cols} jump {jump}")
+        assert_points_equal(small, rsmall, f"cloud_small {rows}x{cols} jump {jump}")
+
+
 @pytest.mark.parametrize("slabs", [None, "0", "s0", "s2", "s7"])
 def test_slab_layout_of_the_fused_batch_path_stays_bit_exact(orc, monkeypatch, slabs):
     """the fused batch path writes the points of an emit tile layout class by layout class (grid slabs along the world
