@@ -165,6 +165,9 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
     const int64_t cap = v.cap;
     const int n_sort_tiles = cdiv64(cap, kSortTile);
     const int n_seg_tiles = cdiv64(cap, kSegTile);
+    // tile-major histogram rows (hist_at in kernels/radix_sort.inc) where a frame's row fits the one-workgroup scan's LDS
+    const size_t tm_lds = (size_t)n_sort_tiles * (kMaxRadix + 1) * sizeof(uint32_t);
+    const int tm = tm_lds <= 48 * 1024 ? 1 : 0;
     if (!v.keys_ready) {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         k_voxel_geom<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, v.mm_used, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2],
@@ -207,30 +210,34 @@ void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelAr
             {
                 ProfScope ps(pf, O3DR_K_KEYGEN, s);  // a cloud left to the point sort needs PCL's index per point after all
                 k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap, ws.keys[0],
-                                                                 n_sort_tiles, ws.hist, ws.hist_part, ws.geom_runs);
+                                                                 n_sort_tiles, ws.hist, ws.hist_part, ws.geom_runs, tm);
             }
         } else if (!v.keys_ready) {  // PCL's index per point and the histogram of the first radix pass
             ProfScope ps(pf, O3DR_K_KEYGEN, s);
             k_voxel_keys_hist0<<<grid, kSortThreads, 0, s>>>(v.in, v.in_fstride, ws.geom, v.z_offset, cap, ws.keys[0],
-                                                             n_sort_tiles, ws.hist, ws.hist_part, nullptr);
+                                                             n_sort_tiles, ws.hist, ws.hist_part, nullptr, tm);
         }
         // always kMaxPasses launch groups; frames whose index needs fewer passes drop out on the device
         const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
+
         for (int pass = 0; pass < kMaxPasses; ++pass) {
             if (!(pass == 0 && !use_runs && !v.keys_ready)) {  // (k_voxel_keys_hist0 counted the first pass's digits)
                 ProfScope ps(pf, O3DR_K_SORT_HIST, s);
                 k_radix_hist<<<grid, kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, sort_geom, pass, n_sort_tiles,
-                                                          ws.hist, ws.hist_part);
+                                                          ws.hist, ws.hist_part, tm);
             }
             {
                 ProfScope ps(pf, O3DR_K_OTHER, s);
-                launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, sort_geom, pass,
-                            n_sort_tiles);
+                if (tm)
+                    k_scan_hist_tm<<<F, 1024, tm_lds, s>>>(ws.hist, sort_geom, pass, n_sort_tiles);
+                else
+                    launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, sort_geom, pass,
+                                n_sort_tiles);
             }
             {
                 ProfScope ps(pf, O3DR_K_SORT_SCATTER, s);
                 k_radix_scatter_lane<<<dim3(xcd_grid((int64_t)n_sort_tiles * kScatParts), F), kScatThreads, 0, s>>>(
-                    ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, sort_geom, pass, n_sort_tiles, ws.hist, ws.hist_part);
+                    ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, sort_geom, pass, n_sort_tiles, ws.hist, ws.hist_part, tm);
             }
         }
         const dim3 sgrid(n_seg_tiles, F);
@@ -390,10 +397,10 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     (void)hipMemsetAsync(ws.sor_cell_end, 0, (size_t)ws.sor_max_cells * 4, s);
     k_sor_cells<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.sor_geom, ws.keys[0]);
     for (int pass = 0; pass < kMaxPasses; ++pass) {
-        k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part);
+        k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part, 0);
         launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
         k_radix_scatter_lane<<<dim3(xcd_grid((int64_t)n_sort_tiles * kScatParts), 1), kScatThreads, 0, s>>>(
-            ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part);
+            ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part, 0);
     }
     k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
                                                      ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);
