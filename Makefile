@@ -11,7 +11,7 @@ HOST     := online_3d_reconstruction_amd/host
 
 all: $(LIBDIR)/libo3dr.so $(BINDIR)/pose oracle
 
-$(LIBDIR)/libo3dr.so: $(CSRC)/o3dr_kernels.hip $(wildcard $(CSRC)/kernels/*.inc) $(CSRC)/o3dr_api.hip $(CSRC)/o3dr_device.h $(CSRC)/o3dr_profile.h include/o3dr.h
+$(LIBDIR)/libo3dr.so: $(CSRC)/o3dr_kernels.hip $(wildcard $(CSRC)/kernels/*.inc) $(CSRC)/o3dr_api.hip $(CSRC)/o3dr_device.h $(CSRC)/o3dr_profile.h include/o3dr.h include/o3dr_testing.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/o3dr_kernels.hip $(CSRC)/o3dr_api.hip -o $@
 

@@ -24,7 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; what a plain device copy reaches on the box is measured below
+                       # (roofline.measured_copy_GBps: 4.7-5.6 TB/s read+write over the boxes seen so far)
 
 
 def _gen(args):
@@ -46,6 +48,14 @@ def generate_frames(start, count, rows, cols, invalid, workers):
         for i, j in enumerate(jobs):
             disp[i], bgr[i] = _gen(j)
     return disp, bgr
+
+
+def _grid_shape(rows, cols, jump, bb=20, cutout=8):
+    """(Ny, Nx) of the grid pass, pose_functions.cpp:1094-1096,638"""
+    cs = int(cols / cutout)
+    if jump <= 0:
+        return 0, 0
+    return max(0, -(-(rows - 2 * bb) // jump)), max(0, -(-(cols - bb - cs) // jump))
 
 
 def kernel_sources_sha1():
@@ -73,6 +83,33 @@ def cpu_baseline(disp, bgr, poses, Q, voxel_size, jump, threads, n_frames, sor=F
     return n_frames / dt, dt
 
 
+def compare_clouds_by_cell(got, ref, voxel_size):
+    """Two merged clouds (one point per XY cell, ascending cell order) -> how far apart they are.  Cells are matched by
+    their (ix, iy) index so that the comparison still means something if the two differ in occupancy."""
+    vs = np.float32(voxel_size)
+
+    def cell_ids(c):
+        return (np.floor(c["y"] / vs).astype(np.int64) << 32) + (np.floor(c["x"] / vs).astype(np.int64) & 0xFFFFFFFF)
+
+    ka, kb = cell_ids(got), cell_ids(ref)
+    same_cells = len(ka) == len(kb) and bool(np.array_equal(ka, kb))
+    if same_cells:
+        ia = ib = slice(None)
+        common = len(ka)
+    else:
+        _, ia, ib = np.intersect1d(ka, kb, assume_unique=False, return_indices=True)
+        common = len(ia)
+    a, b = got[ia], ref[ib]
+    out = {"count_equal": len(got) == len(ref), "cells_equal": same_cells, "cells_compared": int(common),
+           "rgba_equal": bool(np.array_equal(a["rgba"], b["rgba"])),
+           "rgba_differing_cells": int((a["rgba"] != b["rgba"]).sum())}
+    for ax in "xyz":
+        d = np.abs(a[ax].astype(np.float64) - b[ax].astype(np.float64))
+        out["max_abs_d" + ax] = float(d.max()) if common else 0.0
+        out["mean_abs_d" + ax] = float(d.mean()) if common else 0.0
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +131,10 @@ def main():
                     "(--blur_kernel of the reference, README.md:50 uses 30); informational, implies --no-cpu-baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (cpu_baseline AND the bit-for-bit "
                     "verification of the GPU clouds against the oracle, which reuses it)")
+    ap.add_argument("--no-reference-order", action="store_true", help="skip the comparison with the oracle run in the "
+                    "reference's own (libstdc++ std::sort) summation order")
+    ap.add_argument("--no-sor-leg", action="store_true", help="skip the extra leg with statistical outlier removal on")
+    ap.add_argument("--sor-cpu-frames", type=int, default=7, help="frames of the CPU sample with outlier removal on")
     ap.add_argument("--no-pcie-step", action="store_true", help="skip the extra untimed step with HOST inputs "
                     "(pcie_inclusive_frames_per_sec)")
     ap.add_argument("--host-inputs", action="store_true",
@@ -126,7 +167,27 @@ def main():
         scaling = "strong"
     F = args.frames
     first = rank * F  # contiguous block of frames per rank
-    disp_h, bgr_h = generate_frames(first, F, args.rows, args.cols, args.invalid_frac, args.gen_workers)
+    n_cand_host = (lambda g: g[0] * g[1])(_grid_shape(args.rows, args.cols, args.jump_pixels))
+
+    def host_can_verify(total_frames):
+        # the oracle holds all ranks' cloud_big twice and its sort records: ~3.5 x 16 bytes per candidate point
+        try:
+            import psutil
+            need = 3.5 * 16 * n_cand_host * total_frames + 4.0 * args.rows * args.cols * total_frames
+            return psutil.virtual_memory().available > 1.25 * need
+        except Exception:
+            return total_frames <= 400
+
+    # N > 1: rank 0 checks the merged cloud against the oracle's run over the frames of ALL ranks; they are generated
+    # here, before anything touches the GPU (the generator forks a process pool)
+    all_disp = all_bgr = None
+    verify_all = (rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1 and
+                  F * world <= args.verify_max_frames and host_can_verify(F * world))
+    if verify_all:
+        all_disp, all_bgr = generate_frames(0, F * world, args.rows, args.cols, args.invalid_frac, args.gen_workers)
+        disp_h, bgr_h = all_disp[:F], all_bgr[:F]
+    else:
+        disp_h, bgr_h = generate_frames(first, F, args.rows, args.cols, args.invalid_frac, args.gen_workers)
     poses_h = synth.make_poses(first, F)
     Q = synth.camera_Q(args.rows, args.cols)
 
@@ -248,7 +309,7 @@ def main():
     achieved = bytes_per_step[dom_name] * args.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": None, "traffic_from_profile": None, "traffic_measured_in_this_run": False,
                 "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 2), "launches": int(dom_launches),
                 "algorithmic_bytes_per_launch": int(bytes_per_step[dom_name] * args.steps / max(dom_launches, 1))}
     # what a plain device-to-device copy reaches on this box (read + write bytes): context for `peak`
@@ -270,14 +331,16 @@ def main():
         roofline["measured_copy_GBps"] = None
     # HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
     # MI355X_MICROARCH.md "HBM"); only reported when that file was measured on the same kernel sources as this run
-    traffic_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    # (a stored, builder-side measurement: `traffic_from_profile` says so; this run itself collects no PMC counters)
+    traffic_file = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     roofline["traffic_source"] = None
     if os.path.exists(traffic_file):
         try:
             tj = json.load(open(traffic_file))
             if tj.get("kernel") == dom_name and tj.get("kernel_sources_sha1") == kernel_sources_sha1():
-                roofline["traffic"] = tj.get("hbm_bytes_per_launch")
-                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command)"
+                roofline["traffic"] = roofline["traffic_from_profile"] = tj.get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = ("profiles/" + PMC_TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                              "bench command on the same device sources, collected by the builder: not measured in this run)")
         except Exception:
             pass
     # SURVEY 8d end-to-end figure: B_frame = 4N + 16Nv + 16Nv + 16M1 per frame, B_final = 16 SUM(M1) + 16 M2
@@ -315,6 +378,44 @@ def main():
             torch.cuda.synchronize()
             result["pcie_inclusive_frames_per_sec"] = round(F / (time.perf_counter() - t0), 2)
 
+    # ---- the reference's literal per-frame path: statistical outlier removal ON (pose_functions.cpp:1673-1686 runs it in
+    # every per-frame call when jump_pixels > 0).  Reported next to the headline, which is measured with it off.
+    sor_leg = (world == 1 and not args.sor and not args.no_sor_leg and not args.host_inputs and args.jump_pixels > 0 and
+               args.blur_kernel <= 1)
+    if sor_leg:
+        prm_on = o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size, min_points_per_voxel=args.min_points,
+                             sor_enable=True, blur_kernel=args.blur_kernel)
+        ctx.set_params(prm_on)
+        for k in range(2):  # (the first pass allocates the outlier removal's workspaces)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.cloudBigReset()
+            ctx.accumulateFrames(disp, bgr, poses)
+            n_sor = int(ctx.finalize(device=dev).shape[0])
+            torch.cuda.synchronize()
+            result["sor_on_frames_per_sec"] = round(F / (time.perf_counter() - t0), 2)
+        result["sor_on"] = {"frames": F, "merged_cells": n_sor,
+                            "what": "same frames, one untimed-in-`value` step with sor_enable=1 (mean_k 50, 1 sigma), inputs in HBM"}
+        if rank == 0 and not args.no_cpu_baseline:
+            from oracle import orc
+            ns = max(1, min(args.sor_cpu_frames, F))
+            t0 = time.perf_counter()
+            rbig, rsmall = orc.run_frames(disp_h[:ns], bgr_h[:ns], Q, poses_h[:ns], args.voxel_size, jump_pixels=args.jump_pixels,
+                                          min_points_per_voxel=args.min_points, sor=True, threads=args.cpu_threads)
+            t_sor = time.perf_counter() - t0
+            ctx.cloudBigReset()
+            ctx.accumulateFrames(disp[:ns], bgr[:ns], poses[:ns])
+            gbig = ctx.cloudBigRead()
+            gsmall = o3dr.api.points_from_torch(ctx.finalize(device=dev))
+            result["sor_on"].update({
+                "verified": bool(len(gbig) == len(rbig) and np.array_equal(gbig.view(np.uint32), rbig.view(np.uint32)) and
+                                 len(gsmall) == len(rsmall) and np.array_equal(gsmall.view(np.uint32), rsmall.view(np.uint32))),
+                "verified_frames": ns, "cpu_frames_per_sec": round(ns / t_sor, 3), "cpu_threads": args.cpu_threads,
+                "cpu_seconds": round(t_sor, 1)})
+            del rbig, gbig
+        ctx.set_params(o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size, min_points_per_voxel=args.min_points,
+                                   sor_enable=args.sor, blur_kernel=args.blur_kernel))
+
     # ---- verification: the whole step of the headline config against the oracle, bit for bit -----------------------
     result["verified"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
@@ -335,36 +436,69 @@ def main():
                                   "cloud_big_bit_equal": bool(ok_big), "merged_points": int(len(small)),
                                   "oracle_merged_points": int(len(rsmall)), "merged_bit_equal": bool(ok_small),
                                   "oracle_seconds": round(t_or, 2)}
-        del big, rbig
+        del big
+        # The reference's REAL summation order: PCL sorts its (index, point) records with std::sort, which is not stable
+        # (pose_functions.cpp:1700), after z += 500 in fp32 (:1664-1666).  No fixture of the reference pins that order;
+        # the oracle reproduces the libstdc++ call (oracle/o3dr_oracle_stdsort.cpp).  Two comparisons of the GPU's merged
+        # cloud: (a) the same cloud_big merged in std::sort order, (b) the whole pipeline (per-frame grids too) in it.
+        if not args.no_reference_order:
+            t0 = time.perf_counter()
+            std_small, _ = orc.downsample_pt_cloud(rbig, args.voxel_size, True, args.min_points, orc.ORDER_STDSORT)
+            cmp_a = compare_clouds_by_cell(small, std_small, args.voxel_size)
+            del std_small
+            _, std_all = orc.run_frames(disp_h, bgr_h, Q, poses_h, args.voxel_size, jump_pixels=args.jump_pixels,
+                                        min_points_per_voxel=args.min_points, sor=args.sor, threads=args.cpu_threads,
+                                        order=orc.ORDER_STDSORT)
+            cmp_b = compare_clouds_by_cell(small, std_all, args.voxel_size)
+            del std_all
+            cmp_a["points_per_cell"] = cmp_b["points_per_cell"] = round(len(rbig) / max(len(small), 1), 1)
+            cmp_a["what"] = "GPU merged cloud vs the oracle's merge of the SAME cloud_big in libstdc++ std::sort order"
+            cmp_b["what"] = ("GPU merged cloud vs the oracle's whole run (per-frame grids and merge) in libstdc++ std::sort "
+                             "order: the reference's own arithmetic as far as it can be restated here")
+            result["verification"]["vs_reference_sort_order"] = cmp_a
+            result["verification"]["vs_reference_sort_order_whole_pipeline"] = cmp_b
+            result["verification"]["reference_order_seconds"] = round(time.perf_counter() - t0, 2)
+        del rbig
 
-    # ---- N > 1: the merged cloud every rank holds after the exchange against the oracle's run over ALL ranks' frames ---
-    def host_can_verify(total_frames):
-        # the oracle holds all ranks' cloud_big twice and its sort records: ~3.5 x 16 bytes per candidate point
-        try:
-            import psutil
-            need = 3.5 * 16 * n_cand * total_frames + 4.0 * args.rows * args.cols * total_frames
-            return psutil.virtual_memory().available > 1.25 * need
-        except Exception:
-            return total_frames <= 400
-
-    if rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1 and not (
-            F * world <= args.verify_max_frames and host_can_verify(F * world)):
+    # ---- N > 1: every rank's shard of cloud_big (hashed) and the merged cloud every rank holds after the exchange against
+    # the oracle's run over the frames of ALL ranks
+    if world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
+        import hashlib
+        ctx.cloudBigReset()
+        ctx.accumulateFrames(disp, bgr, poses)
+        shard = ctx.cloudBigRead()  # this rank's frames' per-frame voxels, before any exchange
+        mine = np.zeros(28, np.uint8)
+        mine[:8] = np.frombuffer(np.int64(len(shard)).tobytes(), np.uint8)
+        mine[8:] = np.frombuffer(hashlib.sha1(shard.tobytes()).digest(), np.uint8)
+        cd = comm_dev or dev
+        allh = torch.empty(world * 28, dtype=torch.uint8, device=cd)
+        dist.all_gather_into_tensor(allh, torch.from_numpy(mine).to(cd))
+        allh = allh.cpu().numpy().reshape(world, 28)
+        del shard
+    if rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1 and not verify_all:
         result["verification"] = {"skipped": f"{F * world} frames in all: above --verify-max-frames or the host's free memory"}
     elif rank == 0 and world > 1 and not args.no_cpu_baseline and args.blur_kernel <= 1:
         from oracle import orc
-        all_disp, all_bgr = generate_frames(0, F * world, args.rows, args.cols, args.invalid_frac, args.gen_workers)
         all_poses = synth.make_poses(0, F * world)
         t0 = time.perf_counter()
         rbig, rsmall = orc.run_frames(all_disp, all_bgr, Q, all_poses, args.voxel_size, jump_pixels=args.jump_pixels,
                                       min_points_per_voxel=args.min_points, sor=args.sor, threads=args.cpu_threads)
         t_or = time.perf_counter() - t0
         small = o3dr.api.points_from_torch(state["out"])
-        ok_big = int(m1_total) == len(rbig)
+        counts = [int(np.frombuffer(allh[r, :8].tobytes(), np.int64)[0]) for r in range(world)]
+        ok_big = sum(counts) == len(rbig) == int(m1_total)
+        shard_ok = []
+        off = 0
+        for r in range(world):  # the oracle's cloud_big is in frame order = rank order
+            seg = rbig[off: off + counts[r]] if ok_big else rbig[:0]
+            shard_ok.append(bool(ok_big and hashlib.sha1(seg.tobytes()).digest() == allh[r, 8:].tobytes()))
+            off += counts[r]
         ok_small = len(small) == len(rsmall) and np.array_equal(small.view(np.uint32), rsmall.view(np.uint32))
-        result["verified"] = bool(ok_big and ok_small)
+        result["verified"] = bool(ok_big and all(shard_ok) and ok_small)
         result["verification"] = {"against": "oracle/o3dr_oracle.c (orc_run_frames) on the frames and poses of all ranks",
                                   "cloud_big_points_all_ranks": int(m1_total), "oracle_cloud_big_points": int(len(rbig)),
-                                  "cloud_big_count_equal": bool(ok_big), "merged_points": int(len(small)),
+                                  "cloud_big_count_equal": bool(ok_big), "cloud_big_shard_sha1_equal": shard_ok,
+                                  "merged_points": int(len(small)),
                                   "oracle_merged_points": int(len(rsmall)), "merged_bit_equal": bool(ok_small),
                                   "oracle_seconds": round(t_or, 2)}
         del rbig, all_disp, all_bgr
@@ -379,6 +513,10 @@ def main():
                                             f"{args.cpu_threads} frame-parallel threads as pose.cpp:392-413, then the combined "
                                             f"merge), {t7:.1f} s; single thread: {v1:.3f} frames/s on {n1} frames",
                                   "single_thread_value": round(v1, 3), "host_cores": os.cpu_count()}
+        if "sor_on" in result and "cpu_frames_per_sec" in result["sor_on"]:
+            result["cpu_baseline"]["sor_on_value"] = result["sor_on"]["cpu_frames_per_sec"]
+            result["cpu_baseline"]["sor_on_sample"] = (f"first {result['sor_on']['verified_frames']} frames with statistical outlier "
+                                                       f"removal on, {args.cpu_threads} threads, {result['sor_on']['cpu_seconds']} s")
         # all cores of this host (frame-parallel part only scales; the merge is one thread, as in
         # the reference), plus what the host is
         try:
@@ -393,6 +531,8 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if result.get("sor_on", {}).get("verified") is False:
+        sys.exit("bench.py: with outlier removal on, the GPU clouds differ from the oracle's (see `sor_on` in the JSON line)")
     if result.get("verified") is False:
         sys.exit("bench.py: the GPU clouds differ from the oracle's (see `verification` in the JSON line)")
 

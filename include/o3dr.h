@@ -281,10 +281,6 @@ int o3dr_profile_reset(o3dr_ctx* ctx);
  * voxel grids, out[2] = points that left them, out[3] = 0, out[4] = records that entered the sorts (points or runs
  * of points), out[5..7] = 0. */
 int o3dr_profile_stats(o3dr_ctx* ctx, int64_t out[8]);
-/* Test hook for the gather guards: the next o3dr_voxel_grid / o3dr_downsample_pt_cloud / o3dr_finalize of this
- * context finds one of its sorted payloads pointing outside the cloud, as a bookkeeping error upstream would leave it.
- * That call must return O3DR_ERR_INTERNAL with *n_out = 0 (never a GPU fault), and the context stays usable. */
-int o3dr_test_corrupt_next_gather(o3dr_ctx* ctx);
 /* device name / arch / CU count of the context's device, for bench headers */
 int o3dr_device_info(o3dr_ctx* ctx, char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
 

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/o3dr_testing.h"
 #include "o3dr_device.h"
 #include "o3dr_profile.h"
 
@@ -110,6 +111,7 @@ struct o3dr_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: consumed by the next voxel grid
+    int test_hooks = 0;    // O3DR_TEST_HOOKS=1 at o3dr_ctx_create: the entry points of include/o3dr_testing.h act
     int host_batch = 32;  // frames per upload while the previous batch computes (O3DR_HOST_BATCH_FRAMES)
     Profiler prof;
 };
@@ -347,6 +349,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;       // whole-cloud grids always sort points
     else if (ru_env && atoi(ru_env) == 2) c->use_runs = 2;  // ... always sort runs (default: decided per cloud on the device)
     if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
+    const char* th_env = getenv("O3DR_TEST_HOOKS");
+    c->test_hooks = th_env && atoi(th_env) == 1;
     const char* sl_env = getenv("O3DR_SLABS");
     if (sl_env && sl_env[0] == '0') c->slab_shift_env = -1;
     else if (sl_env && sl_env[0] == 's' && atoi(sl_env + 1) >= 0 && atoi(sl_env + 1) <= 20) c->slab_shift_env = atoi(sl_env + 1);
@@ -1003,6 +1007,36 @@ extern "C" int o3dr_downsample_pt_cloud(o3dr_ctx* c, const o3dr_point* in, int64
 // -------------------------------------------------------------------------------------------------
 // A7: device-resident accumulation
 // -------------------------------------------------------------------------------------------------
+// the group-run head flags of cloud_big: one byte per 4 points (+ slack for the last wave's word), tied to cloud_cap.
+// keep: carry the flags recorded so far over.  On failure the old buffer is gone and nothing is recorded.
+static inline size_t heads_bytes(int64_t points) { return ((size_t)points / 4 + 64 + 3) & ~(size_t)3; }
+static int heads_resize(o3dr_ctx* c, int64_t points, bool keep)
+{
+    if (c->cloud_heads && c->cloud_heads_cap >= points) return O3DR_OK;
+    const size_t bytes = heads_bytes(points);
+    uint32_t* nf = nullptr;
+    if (hipMalloc((void**)&nf, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        nf = nullptr;
+    }
+    if (nf && hipMemsetAsync(nf, 0, bytes, c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(nf);
+        nf = nullptr;
+    }
+    if (c->cloud_heads) {
+        if (nf && keep) {
+            const size_t old = heads_bytes(c->cloud_heads_cap);
+            (void)hipMemcpyAsync(nf, c->cloud_heads, old < bytes ? old : bytes, hipMemcpyDeviceToDevice, c->stream);
+        }
+        (void)hipStreamSynchronize(c->stream);  // earlier launches may still write the old flags
+        (void)hipFree(c->cloud_heads);
+    }
+    c->cloud_heads = nf;
+    c->cloud_heads_cap = nf ? points : 0;
+    return nf ? O3DR_OK : fail(O3DR_ERR_ALLOC, "hipMalloc failed (cloud_big run heads)");
+}
+
 static int cloud_reserve(o3dr_ctx* c, int64_t need)
 {
     if (need <= c->cloud_cap) return O3DR_OK;
@@ -1027,24 +1061,9 @@ static int cloud_reserve(o3dr_ctx* c, int64_t need)
     }
     c->cloud_big = nb;
     c->cloud_cap = want;
-    // the flag buffer follows the cloud's capacity (zeros where nothing was recorded yet)
-    if (c->cloud_box_enable) {
-        const size_t bytes = ((size_t)want / 4 + 64 + 3) & ~(size_t)3;
-        uint32_t* nf = nullptr;
-        if (hipMalloc((void**)&nf, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(O3DR_ERR_ALLOC, "hipMalloc failed (cloud_big run heads)");
-        }
-        HIPCHK(hipMemsetAsync(nf, 0, bytes, c->stream));
-        if (c->cloud_heads) {
-            const size_t old = ((size_t)c->cloud_heads_cap / 4 + 64 + 3) & ~(size_t)3;
-            HIPCHK(hipMemcpyAsync(nf, c->cloud_heads, old < bytes ? old : bytes, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            HIPCHK(hipFree(c->cloud_heads));
-        }
-        c->cloud_heads = nf;
-        c->cloud_heads_cap = want;
-    }
+    // the flag buffer follows the cloud's capacity (zeros where nothing was recorded yet); without it the heads are
+    // simply not recorded (the merge then reads the points for them): never a reason to fail the reservation
+    if (c->cloud_box_enable && heads_resize(c, want, true) != O3DR_OK) c->cloud_heads_valid = false;
     return O3DR_OK;
 }
 
@@ -1100,8 +1119,11 @@ static int cloud_box_clear(o3dr_ctx* c)
                                    -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     HIPCHK(hipMemcpyAsync(c->cloud_box, empty, sizeof empty, hipMemcpyHostToDevice, c->stream));
     c->cloud_box_valid = c->cloud_box_enable != 0;
-    if (c->cloud_heads) HIPCHK(hipMemsetAsync(c->cloud_heads, 0, ((size_t)c->cloud_heads_cap / 4 + 64 + 3) & ~(size_t)3, c->stream));
-    c->cloud_heads_valid = c->cloud_box_enable != 0;
+    // the flag buffer must cover the cloud buffer in use NOW: partition / adopt swap in the alternate buffer, whose
+    // capacity the flags know nothing about (a smaller flag buffer would be written past its end by the next appends)
+    if (c->cloud_box_enable && c->cloud_cap > 0 && c->cloud_heads_cap < c->cloud_cap) (void)heads_resize(c, c->cloud_cap, false);
+    if (c->cloud_heads) HIPCHK(hipMemsetAsync(c->cloud_heads, 0, heads_bytes(c->cloud_heads_cap), c->stream));
+    c->cloud_heads_valid = c->cloud_box_enable != 0 && c->cloud_heads && c->cloud_heads_cap >= c->cloud_cap;
     return O3DR_OK;
 }
 
@@ -1109,6 +1131,10 @@ static int cloud_box_clear(o3dr_ctx* c)
 static void heads_for_append(o3dr_ctx* c, VoxelArgs& v)
 {
     if (!c->cloud_heads_valid || !c->cloud_heads) return;
+    if (c->cloud_heads_cap < c->cloud_cap) {  // (never expected: cloud_reserve and cloud_box_clear keep them together)
+        c->cloud_heads_valid = false;
+        return;
+    }
     float leaf[3], zo;
     uint32_t mp;
     downsample_leaf(c->params, 1, leaf, &mp, &zo);
@@ -1659,6 +1685,7 @@ extern "C" int o3dr_disparity_variance(o3dr_ctx* c, const uint8_t* disp, int64_t
 extern "C" int o3dr_test_corrupt_next_gather(o3dr_ctx* c)
 {
     CTX_ENTER(c);
+    if (!c->test_hooks) return fail(O3DR_ERR_INVALID_ARG, "test hooks are off (create the context with O3DR_TEST_HOOKS=1)");
     c->test_corrupt = 1;
     return O3DR_OK;
 }

@@ -502,7 +502,7 @@ int64_t orc_statistical_outlier_removal(const orc_point* in, int64_t n, int32_t 
 typedef struct frame_job {
     const uint8_t *disp, *bgr;
     int64_t disp_fstride, disp_pitch, bgr_fstride, bgr_pitch;
-    int32_t rows, cols, bb, cs, jump, n_frames, sor;
+    int32_t rows, cols, bb, cs, jump, n_frames, sor, order;
     const double* Q;
     double min_disp, voxel_size;
     const float* poses;
@@ -526,14 +526,14 @@ static void* frame_worker(void* arg)
         int64_t n;
         if (!j->sor) {
             n = orc_create_and_transform_pt_cloud(d, j->disp_pitch, c, j->bgr_pitch, j->rows, j->cols, j->Q, j->bb, j->cs,
-                                                  j->min_disp, j->jump, NULL, 0, T, j->voxel_size, 0, ORC_ORDER_STABLE,
+                                                  j->min_disp, j->jump, NULL, 0, T, j->voxel_size, 0, j->order,
                                                   scratch, tmp, NULL);
         } else {
             const int64_t n0 = orc_create_single_img_pt_cloud(d, j->disp_pitch, c, j->bgr_pitch, j->rows, j->cols, j->Q, j->bb,
                                                               j->cs, j->min_disp, j->jump, NULL, 0, scratch);
             orc_transform_pt_cloud(scratch, n0, T, scratch + n0);
             const int64_t n1 = j->jump > 0 ? orc_statistical_outlier_removal(scratch + n0, n0, 50, 1.0, scratch, NULL, 0) : n0;
-            n = orc_downsample_pt_cloud(j->jump > 0 ? scratch : scratch + n0, n1, j->voxel_size, 0, 0, ORC_ORDER_STABLE, tmp, NULL);
+            n = orc_downsample_pt_cloud(j->jump > 0 ? scratch : scratch + n0, n1, j->voxel_size, 0, 0, j->order, tmp, NULL);
         }
         j->out[f] = (orc_point*)malloc((size_t)(n + 1) * sizeof(orc_point));
         memcpy(j->out[f], tmp, (size_t)n * sizeof(orc_point));
@@ -544,12 +544,12 @@ static void* frame_worker(void* arg)
     return NULL;
 }
 
-int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_pitch, const uint8_t* bgr,
-                       int64_t bgr_fstride, int64_t bgr_pitch, int32_t rows, int32_t cols, const double Q[16],
-                       int32_t bounding_box, int32_t cols_start_aft_cutout, double min_disparity,
-                       int32_t jump_pixels, const float* poses, int32_t n_frames, double voxel_size,
-                       uint32_t min_points_per_voxel, int32_t sor, int32_t threads, orc_point* cloud_big_out,
-                       int64_t* n_big, orc_point* merged_out)
+int64_t orc_run_frames_order(const uint8_t* disp, int64_t disp_fstride, int64_t disp_pitch, const uint8_t* bgr,
+                             int64_t bgr_fstride, int64_t bgr_pitch, int32_t rows, int32_t cols, const double Q[16],
+                             int32_t bounding_box, int32_t cols_start_aft_cutout, double min_disparity,
+                             int32_t jump_pixels, const float* poses, int32_t n_frames, double voxel_size,
+                             uint32_t min_points_per_voxel, int32_t sor, int32_t threads, int32_t order,
+                             orc_point* cloud_big_out, int64_t* n_big, orc_point* merged_out)
 {
     if (n_frames <= 0) return 0;
     if (threads < 1) threads = 1;
@@ -560,7 +560,7 @@ int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_p
     j.disp = disp; j.bgr = bgr;
     j.disp_fstride = disp_fstride; j.disp_pitch = disp_pitch; j.bgr_fstride = bgr_fstride; j.bgr_pitch = bgr_pitch;
     j.rows = rows; j.cols = cols; j.bb = bounding_box; j.cs = cols_start_aft_cutout; j.jump = jump_pixels;
-    j.n_frames = n_frames; j.sor = sor; j.Q = Q; j.min_disp = min_disparity; j.voxel_size = voxel_size; j.poses = poses;
+    j.n_frames = n_frames; j.sor = sor; j.order = order; j.Q = Q; j.min_disp = min_disparity; j.voxel_size = voxel_size; j.poses = poses;
     j.out = (orc_point**)calloc((size_t)n_frames, sizeof(orc_point*));
     j.out_n = (int64_t*)calloc((size_t)n_frames, sizeof(int64_t));
     j.next = &next;
@@ -582,12 +582,24 @@ int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_p
     }
     if (n_big) *n_big = total;
     orc_point* merged = merged_out ? merged_out : (orc_point*)malloc((size_t)(total + 1) * sizeof(orc_point));
-    const int64_t m = orc_downsample_pt_cloud(big, total, voxel_size, 1, min_points_per_voxel, ORC_ORDER_STABLE, merged, NULL);
+    const int64_t m = orc_downsample_pt_cloud(big, total, voxel_size, 1, min_points_per_voxel, order, merged, NULL);
     if (!merged_out) free(merged);
     if (!cloud_big_out) free(big);
     free(j.out);
     free(j.out_n);
     return m;
+}
+
+int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_pitch, const uint8_t* bgr,
+                       int64_t bgr_fstride, int64_t bgr_pitch, int32_t rows, int32_t cols, const double Q[16],
+                       int32_t bounding_box, int32_t cols_start_aft_cutout, double min_disparity,
+                       int32_t jump_pixels, const float* poses, int32_t n_frames, double voxel_size,
+                       uint32_t min_points_per_voxel, int32_t sor, int32_t threads, orc_point* cloud_big_out,
+                       int64_t* n_big, orc_point* merged_out)
+{
+    return orc_run_frames_order(disp, disp_fstride, disp_pitch, bgr, bgr_fstride, bgr_pitch, rows, cols, Q, bounding_box,
+                                cols_start_aft_cutout, min_disparity, jump_pixels, poses, n_frames, voxel_size,
+                                min_points_per_voxel, sor, threads, ORC_ORDER_STABLE, cloud_big_out, n_big, merged_out);
 }
 
 

@@ -90,6 +90,15 @@ int64_t orc_run_frames(const uint8_t* disp, int64_t disp_fstride, int64_t disp_p
                        uint32_t min_points_per_voxel, int32_t sor, int32_t threads, orc_point* cloud_big_out,
                        int64_t* n_big, orc_point* merged_out);
 
+/* the same with the summation order of EVERY voxel grid (per frame and merge) chosen: ORC_ORDER_STDSORT is the
+ * reference's actual std::sort order (pose_functions.cpp:1700), which no fixture of the reference pins */
+int64_t orc_run_frames_order(const uint8_t* disp, int64_t disp_fstride, int64_t disp_pitch, const uint8_t* bgr,
+                             int64_t bgr_fstride, int64_t bgr_pitch, int32_t rows, int32_t cols, const double Q[16],
+                             int32_t bounding_box, int32_t cols_start_aft_cutout, double min_disparity,
+                             int32_t jump_pixels, const float* poses, int32_t n_frames, double voxel_size,
+                             uint32_t min_points_per_voxel, int32_t sor, int32_t threads, int32_t order,
+                             orc_point* cloud_big_out, int64_t* n_big, orc_point* merged_out);
+
 /* A1 pre-pass — cv::bilateralFilter(disp, out, d, sigma_color, sigma_space) as called at
  * pose_functions.cpp:1040-1047 with (blur_kernel, blur_kernel*2, blur_kernel/2): OpenCV 3.1.0
  * modules/imgproc/src/smooth.cpp bilateralFilter_8u, single channel, BORDER_DEFAULT (reflect-101),

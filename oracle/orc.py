@@ -53,6 +53,9 @@ def lib():
         L.orc_run_frames.restype = i64
         L.orc_run_frames.argtypes = [vp, i64, i64, vp, i64, i64, i32, i32, vp, i32, i32, dbl, i32, vp, i32, dbl, u32, i32, i32,
                                      vp, vp, vp]
+        L.orc_run_frames_order.restype = i64
+        L.orc_run_frames_order.argtypes = [vp, i64, i64, vp, i64, i64, i32, i32, vp, i32, i32, dbl, i32, vp, i32, dbl, u32, i32, i32,
+                                           i32, vp, vp, vp]
         L.orc_voxel_keys.restype = u32
         L.orc_voxel_keys.argtypes = [vp, i64, vp, vp, vp, vp]
         L.orc_bilateral_filter_u8.restype = None
@@ -169,9 +172,10 @@ def statistical_outlier_removal(pts, mean_k=50, stddev_mul=1.0, brute=False):
 
 
 def run_frames(disp, bgr, Q, poses, voxel_size, jump_pixels=1, min_points_per_voxel=1, sor=False, threads=7,
-               bounding_box=20, cutout_ratio=8, min_disparity=64.0, want_clouds=True):
+               bounding_box=20, cutout_ratio=8, min_disparity=64.0, want_clouds=True, order=ORDER_STABLE):
     """A7 + final merge with the reference's thread fan-out, inside the C oracle (pthreads).
-    Returns (cloud_big, merged) or just the merged count when want_clouds is False (timing)."""
+    Returns (cloud_big, merged) or just the merged count when want_clouds is False (timing).
+    order: summation order of every voxel grid (ORDER_STDSORT = the reference's own std::sort order)."""
     disp = np.ascontiguousarray(disp, np.uint8)
     bgr = np.ascontiguousarray(bgr, np.uint8)
     poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
@@ -183,10 +187,10 @@ def run_frames(disp, bgr, Q, poses, voxel_size, jump_pixels=1, min_points_per_vo
     if want_clouds:
         big = np.empty(max(F * ny * nx, 1), POINT)
         merged = np.empty(max(F * ny * nx, 1), POINT)
-    m = lib().orc_run_frames(_p(disp), disp.strides[0], disp.strides[1], _p(bgr), bgr.strides[0], bgr.strides[1], rows, cols,
-                             _p(Q), bounding_box, cs, float(min_disparity), jump_pixels, _p(poses), F, float(voxel_size),
-                             min_points_per_voxel, int(bool(sor)), threads, _p(big) if want_clouds else None,
-                             C.byref(n_big), _p(merged) if want_clouds else None)
+    m = lib().orc_run_frames_order(_p(disp), disp.strides[0], disp.strides[1], _p(bgr), bgr.strides[0], bgr.strides[1], rows,
+                                   cols, _p(Q), bounding_box, cs, float(min_disparity), jump_pixels, _p(poses), F,
+                                   float(voxel_size), min_points_per_voxel, int(bool(sor)), threads, int(order),
+                                   _p(big) if want_clouds else None, C.byref(n_big), _p(merged) if want_clouds else None)
     if want_clouds:
         return big[: n_big.value].copy(), merged[:m].copy()
     return m

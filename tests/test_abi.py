@@ -11,7 +11,8 @@ from conftest import ROOT
 
 
 def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "o3dr.h")).read()
+    import glob
+    txt = "".join(open(h).read() for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(o3dr_[a-z0-9_]+)\s*\(", txt)))
 
@@ -22,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     L = C.CDLL(_lib.lib_path())
     for n in names:
-        assert hasattr(L, n), f"{n} is declared in include/o3dr.h but not exported by libo3dr.so"
+        assert hasattr(L, n), f"{n} is declared in include/*.h but not exported by libo3dr.so"
     bound = sorted(n for n, _, _ in _lib.SYMBOLS)
     assert bound == names, set(bound) ^ set(names)
 

@@ -2,6 +2,8 @@
 inputs.  Bar: BIT-EXACT (coordinates, colours, order, counts) against the oracle's canonical
 summation order; the oracle's std::sort variant (the reference's unspecified order) is compared at
 the 1e-4 m tolerance of BASELINE.json where the domain allows it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -151,10 +153,9 @@ def test_A3a_A5_downsample_pt_cloud(ctx, orc, Q, frame_1248, vs, minpts):
     assert len(np.unique(cells, axis=0)) == len(comb)
 
 
-def test_A5_within_tolerance_of_reference_sort_order(ctx, orc):
-    """against the oracle's libstdc++ std::sort variant (the reference's actual, unspecified,
-    summation order): identical occupancy and colours, coordinates within 1e-4 m for per-frame
-    voxels; the combined mode's z is summed at +500 in fp32 and is noise-limited."""
+def test_A3a_within_tolerance_of_reference_sort_order(ctx, orc):
+    """per-frame mode against the oracle's libstdc++ std::sort variant (the reference's actual, unspecified,
+    summation order): identical occupancy and colours, coordinates within 1e-4 m"""
     pts = random_cloud(400000, 44, extent=(6.0, 4.0, 1.0))
     ctx.set_params(_params(voxel_size=0.05))
     got = ctx.downsamplePtCloud(pts, False)
@@ -162,6 +163,34 @@ def test_A5_within_tolerance_of_reference_sort_order(ctx, orc):
     assert len(got) == len(ref) and np.array_equal(got["rgba"], ref["rgba"])
     for ax in "xyz":
         assert np.abs(got[ax].astype(np.float64) - ref[ax]).max() <= TOL_M
+
+
+# what the combined merge can agree to with the reference's own std::sort order at the headline density (~220 points
+# per cell): z is summed at +500 in fp32 (pose_functions.cpp:1664-1666), partial sums reach ~1.1e5 where one ulp is
+# 2^-7 m, and ANY two summation orders differ by a random walk of such roundings.  Measured here (stable vs std::sort,
+# 229 points per cell, 9600 cells): max |dz| 4.9e-4 m, mean 1.0e-4 m; x / y (sums of ~1e3) below 1e-5 m.
+A5_Z_BOUND_M = 1e-3
+
+
+def test_A5_combined_mode_against_reference_sort_order(ctx, orc):
+    """A5 proper: downsamplePtCloud(pts, true) at >= 200 points per cell against ORDER_STDSORT (pose_functions.cpp:
+    1664-1666,1693-1704 with PCL's unstable std::sort): exact occupancy, order and colours; x / y within 1e-5 m; z within
+    the bound fp32 summation at +500 m allows, which is ABOVE north_star's 1e-4 m."""
+    pts = random_cloud(2_200_000, 44, extent=(6.0, 4.0, 1.0))
+    ctx.set_params(_params(voxel_size=0.05))
+    got = ctx.downsamplePtCloud(pts, True)
+    stable, _ = orc.downsample_pt_cloud(pts, 0.05, True, 1, orc.ORDER_STABLE)
+    assert_points_equal(got, stable, "combined merge, canonical order")
+    ref, _ = orc.downsample_pt_cloud(pts, 0.05, True, 1, orc.ORDER_STDSORT)
+    assert len(pts) / len(got) >= 200
+    assert len(got) == len(ref) and np.array_equal(got["rgba"], ref["rgba"])
+    vs = np.float32(0.05)
+    for ax in "xy":  # same cells in the same order
+        assert np.array_equal(np.floor(got[ax] / vs), np.floor(ref[ax] / vs))
+        assert np.abs(got[ax].astype(np.float64) - ref[ax]).max() <= 1e-5
+    dz = np.abs(got["z"].astype(np.float64) - ref["z"])
+    assert dz.max() <= A5_Z_BOUND_M, dz.max()
+    assert dz.max() > TOL_M  # (the point of the test: the reference's own result is not defined to 1e-4 m here)
 
 
 # ---- A6 ------------------------------------------------------------------------------------------
@@ -275,14 +304,15 @@ def test_config4_overflow_frames_pass_through(ctx, orc):
     ctx.set_camera(synth.camera_Q())
 
 
-# ---- size-independent properties at BASELINE's full dense size -----------------------------------
-def test_full_size_properties(ctx):
-    """200-frame dense config is too slow for the scalar oracle; check what the domain guarantees:
-    counts, sortedness by voxel index, one point per XY cell, idempotent occupancy, bounding box."""
+# ---- BASELINE's full dense size (configs[1]): 200 frames, against the oracle and through size-independent properties --
+def test_full_size_config1_200_frames(ctx, orc):
+    """the headline workload itself: 200 dense 720p frames -> cloud_big (98 M points) -> merged cloud, bit for bit
+    against orc.run_frames; plus what the domain guarantees (sortedness by voxel index, one point per XY cell,
+    idempotent occupancy, bounding box)."""
     from online_3d_reconstruction_amd import synth
     Qs = synth.camera_Q()
     ctx.set_camera(Qs)
-    F = 24
+    F = 200
     disp, bgr = synth.make_frames(0, F)
     poses = synth.make_poses(0, F)
     ctx.set_params(_params(jump_pixels=1, voxel_size=0.05))
@@ -291,30 +321,30 @@ def test_full_size_properties(ctx):
     n, st = ctx.cloudBigSize()
     assert st == 0 and 0 < n <= F * 748000
     small = ctx.finalize()
+    big = ctx.cloudBigRead()
+    rbig, rsmall = orc.run_frames(disp, bgr, Qs, poses, 0.05, jump_pixels=1, threads=min(16, os.cpu_count() or 1))
+    del disp, bgr
+    assert_points_equal(big, rbig, "cloud_big of 200 dense frames")
+    assert_points_equal(small, rsmall, "merged cloud of 200 dense frames")
+    del rbig, rsmall
     vs = np.float32(0.05)
     ix, iy = np.floor(small["x"] / vs).astype(np.int64), np.floor(small["y"] / vs).astype(np.int64)
     lin = iy * (1 << 32) + ix
     assert np.all(np.diff(lin) > 0)  # ascending (y, then x) = PCL's linear index order, no duplicates
     again = ctx.downsamplePtCloud(small, True)
     assert len(again) == len(small) and np.array_equal(again["rgba"], small["rgba"])
-    big = ctx.cloudBigRead()
     assert small["x"].min() >= big["x"].min() and small["x"].max() <= big["x"].max()
     assert np.abs(small["z"]).max() < 30
+    ctx.cloudBigReset()
 
 
 # ---- multi-GPU merge pieces on one GPU: virtual ranks, exchange done by hand ---------------------------
-@pytest.mark.parametrize("world", [2, 3, 5, 8])
-def test_partitioned_merge_virtual_ranks(Q, orc, world):
-    """cloud_big_bbox / cloud_big_partition / finalize_global: W contexts stand in for W ranks; the
-    concatenated slice merges must equal the single-context merge over all frames, bit for bit."""
+def _virtual_rank_merge(Qs, disp, bgr, poses, prm, world):
+    """cloud_big_bbox / cloud_big_partition / finalize_global: `world` contexts stand in for as many ranks, the
+    exchange is done by hand; returns (concatenated slice merges, the single-context merge, per-slice sizes)"""
     import online_3d_reconstruction_amd as o3dr
-    from online_3d_reconstruction_amd import synth
     from online_3d_reconstruction_amd.dist import shard_range
-    Qs = synth.camera_Q()
-    F = 11
-    disp, bgr = synth.make_frames(300, F, invalid_frac=0.01)
-    poses = synth.make_poses(300, F)
-    prm = _params(jump_pixels=3, voxel_size=0.05)
+    F = len(disp)
     with o3dr.Context(0, Q=Qs, params=prm) as one:
         one.accumulateFrames(disp, bgr, poses)
         ref = one.finalize()
@@ -349,8 +379,69 @@ def test_partitioned_merge_virtual_ranks(Q, orc, world):
     finally:
         for c in ctxs:
             c.close()
+    return got, ref, [len(o) for o in outs]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+def test_partitioned_merge_virtual_ranks(Q, orc, world):
+    """W contexts stand in for W ranks; the concatenated slice merges must equal the single-context merge over all
+    frames, bit for bit."""
+    from online_3d_reconstruction_amd import synth
+    F = 11
+    disp, bgr = synth.make_frames(300, F, invalid_frac=0.01)
+    poses = synth.make_poses(300, F)
+    got, ref, sizes = _virtual_rank_merge(synth.camera_Q(), disp, bgr, poses, _params(jump_pixels=3, voxel_size=0.05), world)
     assert_points_equal(got, ref, f"partitioned merge, {world} virtual ranks")
-    assert min(len(o) for o in outs) > 0  # every slice got work
+    assert min(sizes) > 0  # every slice got work
+
+
+@pytest.mark.parametrize("shape", ["config3_dense_720p", "config5_4k_jump4"])
+def test_partitioned_merge_world8_config_shapes(orc, shape):
+    """BASELINE configs[2] and configs[4] shapes through the 8-rank partitioned merge (8 virtual ranks on one GPU, two
+    frames each): dense (jump 1) 1280x720 frames, and 4096x2160 frames at jump_pixels 4; against the single-context
+    merge AND the oracle's run over all frames."""
+    from online_3d_reconstruction_amd import synth
+    world, F = 8, 16
+    if shape == "config3_dense_720p":
+        rows, cols, jump = 720, 1280, 1
+    else:
+        rows, cols, jump = 2160, 4096, 4
+    Qs = synth.camera_Q(rows, cols)
+    disp, bgr = synth.make_frames(40, F, rows, cols, invalid_frac=0.01)
+    poses = synth.make_poses(40, F)
+    got, ref, sizes = _virtual_rank_merge(Qs, disp, bgr, poses, _params(jump_pixels=jump, voxel_size=0.05), world)
+    assert_points_equal(got, ref, f"{shape}: partitioned merge, 8 virtual ranks")
+    assert min(sizes) > 0
+    _, rsmall = orc.run_frames(disp, bgr, Qs, poses, 0.05, jump_pixels=jump, threads=min(16, os.cpu_count() or 1))
+    assert_points_equal(got, rsmall, f"{shape}: partitioned merge vs the oracle")
+
+
+def test_config5_shape_batched_accumulate_and_finalize(ctx, orc):
+    """BASELINE config 5 shape through the BATCHED path: 4 frames of 4096x2160 at jump_pixels 4 (strided rows, generic
+    load path, 472 230 candidates per frame) -> accumulateFrames -> finalize, host and device inputs"""
+    import torch
+    from online_3d_reconstruction_amd import synth
+    rows, cols, F = 2160, 4096, 4
+    Qs = synth.camera_Q(rows, cols)
+    ctx.set_camera(Qs)
+    try:
+        disp, bgr = synth.make_frames(7, F, rows, cols, invalid_frac=0.02)
+        poses = synth.make_poses(7, F)
+        ctx.set_params(_params(jump_pixels=4, voxel_size=0.05))
+        rbig, rsmall = orc.run_frames(disp, bgr, Qs, poses, 0.05, jump_pixels=4, threads=4)
+        for device in (False, True):
+            ctx.cloudBigReset()
+            if device:
+                ctx.accumulateFrames(torch.from_numpy(disp).cuda(), torch.from_numpy(bgr).cuda(), torch.from_numpy(poses).cuda())
+            else:
+                ctx.accumulateFrames(disp, bgr, poses)
+            n, st = ctx.cloudBigSize()
+            assert st == 0
+            assert_points_equal(ctx.cloudBigRead(), rbig, f"config 5 cloud_big (device inputs: {device})")
+            assert_points_equal(ctx.finalize(), rsmall, f"config 5 merged cloud (device inputs: {device})")
+    finally:
+        ctx.set_camera(synth.camera_Q())
+        ctx.cloudBigReset()
 
 
 def test_config5_shape_4k_semidense(ctx, orc):
@@ -1015,6 +1106,41 @@ def test_cloud_big_keeps_its_group_run_heads(ctx, orc):
     ctx.set_params(_params(jump_pixels=1, voxel_size=0.05))
 
 
+def test_run_head_flags_follow_a_swapped_in_cloud_buffer(orc):
+    """The multi-GPU loop (reset, accumulate, partition, exchange, adopt, merge per step): partition / adopt swap the
+    library's second cloud buffer in, whose capacity can be far above the one the group-run head flags were sized for.
+    After the next reset the frame calls record heads for points beyond the OLD capacity without any reallocation of the
+    cloud: the flag buffer must have followed (it used to be written past its end)."""
+    import torch
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    Qs = synth.camera_Q()
+    disp, bgr = synth.make_frames(720, 5, invalid_frac=0.01)
+    poses = synth.make_poses(720, 5)
+    with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=1, voxel_size=0.05)) as c:
+        c.accumulateFrames(disp[:1], bgr[:1], poses[:1])      # cloud_big and its flags: room for one frame
+        n1, _ = c.cloudBigSize()
+        mn, mx, _ = c.cloudBigBBox()
+        counts, st = c.cloudBigPartition(mn, mx, 2)
+        assert st == 0 and sum(counts) == n1
+        send = c.cloudBigView()
+        recv = c.cloudBigRecvBuffer(8 * 748000)                # a peer sent much more than the old capacity holds
+        recv[:n1] = send
+        torch.cuda.synchronize()
+        c.cloudBigAdopt(n1)                                    # the big receive buffer is cloud_big now
+        one_frame = c.finalize(gmin=mn, gmax=mx)
+        assert len(one_frame) > 0
+        c.cloudBigReset()                                      # next step: heads are recorded again
+        c.accumulateFrames(disp, bgr, poses)                   # five frames: far beyond the old flag buffer, no regrow
+        big = c.cloudBigRead()
+        assert len(big) > 3 * 748000 * 0.5
+        c.profileReset()
+        got = c.finalize()
+        stats = c.profileStatsAll()
+        assert_points_equal(got, orc.downsample_pt_cloud(big, 0.05, True, 1)[0], "merge after partition/adopt/reset/regrow")
+        assert stats[4] * 8 <= len(big)  # the merge started from the recorded group runs
+
+
 def test_A7_dont_downsample_accumulates_raw_points(ctx, orc):
     """--dont_downsample (pose.cpp:609, 534-537): cloud_big is the concatenation of the transformed frames and the
     final cloud is cloud_big itself; the tracked bounding box covers the passthrough path too"""
@@ -1041,7 +1167,7 @@ def test_A7_dont_downsample_accumulates_raw_points(ctx, orc):
         ctx.set_params(_params(jump_pixels=5, voxel_size=0.05))
 
 
-def test_error_behaviour_of_the_c_abi(Q, frame_1249):
+def test_error_behaviour_of_the_c_abi(Q, frame_1249, monkeypatch):
     """every failure returns a negative code, leaves *n_out at 0 ("output cloud left empty", pose.cpp:620-635) and
     explains itself through o3dr_last_error; a context stays usable afterwards"""
     import ctypes as C
@@ -1063,6 +1189,10 @@ def test_error_behaviour_of_the_c_abi(Q, frame_1249):
 
     assert call(None) == L.ERR_INVALID_ARG and n.value == 0                       # no context
     assert b"ctx is NULL" in lib.o3dr_last_error()
+    with o3dr.Context(0) as c:  # the test-only entry points (include/o3dr_testing.h) are dead without O3DR_TEST_HOOKS=1
+        assert lib.o3dr_test_corrupt_next_gather(c._h) == L.ERR_INVALID_ARG
+        assert b"test hooks are off" in lib.o3dr_last_error()
+    monkeypatch.setenv("O3DR_TEST_HOOKS", "1")
     with o3dr.Context(0) as c:
         h = c._h
         assert call(h) == L.ERR_NOT_CONFIGURED and n.value == 0                   # camera not set
