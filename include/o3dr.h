@@ -257,6 +257,18 @@ int o3dr_finalize_global(o3dr_ctx* ctx, const float gmin[3], const float gmax[3]
 int o3dr_cloud_big_view(o3dr_ctx* ctx, void** ptr, int64_t* n);
 int o3dr_cloud_big_recv_buffer(o3dr_ctx* ctx, int64_t n_points, void** ptr);
 int o3dr_cloud_big_adopt(o3dr_ctx* ctx, int64_t n_points);
+/* The same two steps with their small data kept in HBM, so that the whole exchange needs ONE host read-back (the
+ * all-to-all's sizes): o3dr_cloud_big_header_dev writes this rank's 32-byte header {float min[3], max[3]; int64 count}
+ * to the DEVICE buffer hdr_dev; after the ranks all-gathered their headers, o3dr_cloud_big_partition_dev folds the
+ * n_hdrs headers at hdrs_dev into the global box and partitions as above, leaving n_parts int64 slice counts
+ * followed by one int64 status word (O3DR_STATUS_VOXEL_OVERFLOW: all counts 0, cloud unchanged) in the DEVICE buffer
+ * counts_dev.  Both are asynchronous on the context's stream.  o3dr_cloud_big_adopt is stream-ordered as well: what
+ * fills the receive buffer must be ordered before the stream's next work by the caller (same stream, or an event).
+ * o3dr_cloud_big_assume_size: the caller read its own header back (with the all-to-all's sizes) and tells the library
+ * the exact size of cloud_big, so that o3dr_cloud_big_view / o3dr_finalize* need no round trip of their own for it. */
+int o3dr_cloud_big_header_dev(o3dr_ctx* ctx, void* hdr_dev);
+int o3dr_cloud_big_assume_size(o3dr_ctx* ctx, int64_t n_points);
+int o3dr_cloud_big_partition_dev(o3dr_ctx* ctx, const void* hdrs_dev, int32_t n_hdrs, int32_t n_parts, int64_t* counts_dev);
 
 /* ---- measurement hooks (bench.py; not part of the reference surface) ------------------------ */
 /* kernel ids for o3dr_profile_* */

@@ -74,6 +74,9 @@ SYMBOLS = [
     ("o3dr_cloud_big_view", C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     ("o3dr_cloud_big_recv_buffer", C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     ("o3dr_cloud_big_adopt", C.c_int, [_vp, _i64]),
+    ("o3dr_cloud_big_header_dev", C.c_int, [_vp, _vp]),
+    ("o3dr_cloud_big_assume_size", C.c_int, [_vp, _i64]),
+    ("o3dr_cloud_big_partition_dev", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("o3dr_profile_enable", C.c_int, [_vp, _i32, _i32]),
     ("o3dr_profile_read", C.c_int, [_vp, _i32, C.POINTER(C.c_double), _pi64]),
     ("o3dr_profile_reset", C.c_int, [_vp]),

@@ -55,6 +55,7 @@ class Context:
         L.check(self._lib.o3dr_ctx_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self.stream_raw = 0
         self.params = Params()
         if Q is not None:
             self.set_camera(Q)
@@ -95,6 +96,7 @@ class Context:
         """stream: a torch.cuda.Stream, a raw hipStream_t integer, or None for the context's own."""
         raw = getattr(stream, "cuda_stream", stream)
         L.check(self._lib.o3dr_ctx_set_stream(self._h, C.c_void_p(raw or 0)))
+        self.stream_raw = int(raw or 0)  # 0: the context's own stream (dist.py orders collectives against it)
 
     def synchronize(self):
         L.check(self._lib.o3dr_ctx_synchronize(self._h))
@@ -360,6 +362,28 @@ class Context:
         """the first n_points of the receive buffer become cloud_big"""
         L.check(self._lib.o3dr_cloud_big_adopt(self._h, int(n_points)))
 
+    def cloudBigHeaderDev(self):
+        """this rank's 32-byte exchange header {min xyz, max xyz (f32), count (i64)} as a uint8 CUDA tensor; asynchronous"""
+        import torch
+        hdr = torch.empty(32, dtype=torch.uint8, device=torch.device("cuda", self.device))
+        L.check(self._lib.o3dr_cloud_big_header_dev(self._h, hdr.data_ptr()))
+        return hdr
+
+    def cloudBigPartitionDev(self, hdrs, n_parts):
+        """hdrs: the all-gathered headers ([world*32] uint8, CUDA).  Stable reorder of cloud_big by index slice of the
+        combined grid over the box the headers span; -> int64 CUDA tensor [n_parts + 1]: slice counts, then the status
+        word.  Asynchronous (no host round trip)."""
+        import torch
+        assert hdrs.is_cuda and hdrs.is_contiguous() and hdrs.numel() % 32 == 0
+        counts = torch.empty(n_parts + 1, dtype=torch.int64, device=hdrs.device)
+        L.check(self._lib.o3dr_cloud_big_partition_dev(self._h, hdrs.data_ptr(), hdrs.numel() // 32, int(n_parts), counts.data_ptr()))
+        self._keep = hdrs  # (the launches read it)
+        return counts
+
+    def cloudBigAssumeSize(self, n_points):
+        """the caller read this rank's header back: cloud_big holds exactly n_points (saves the library its own round trips)"""
+        L.check(self._lib.o3dr_cloud_big_assume_size(self._h, int(n_points)))
+
     def cloudBigBBox(self):
         """(min xyz, max xyz, count) of cloud_big; (+inf, -inf, 0) when empty"""
         mn = np.empty(3, np.float32)
@@ -377,10 +401,11 @@ class Context:
         L.check(self._lib.o3dr_cloud_big_partition(self._h, gmin.ctypes.data, gmax.ctypes.data, n_parts, counts, C.byref(st)))
         return [int(v) for v in counts], st.value
 
-    def finalize(self, device=None, return_status=False, gmin=None, gmax=None):
+    def finalize(self, device=None, return_status=False, gmin=None, gmax=None, n_hint=None):
         """cloud_small = downsamplePtCloud(cloud_big, true) (pose.cpp:530); with gmin/gmax the grid is laid
-        over that (global) bounding box instead of cloud_big's own (multi-GPU merge)."""
-        n, _ = self.cloudBigSize()
+        over that (global) bounding box instead of cloud_big's own (multi-GPU merge).  n_hint: the caller knows
+        cloud_big's size (after an adopt): the output is sized without asking the device."""
+        n = int(n_hint) if n_hint is not None else self.cloudBigSize()[0]
         if device is not None:
             import torch
             out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)

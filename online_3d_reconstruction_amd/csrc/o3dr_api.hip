@@ -76,6 +76,7 @@ struct o3dr_ctx {
     size_t ws_emit_tiles = 0, ws_sort_tiles = 0, ws_seg_tiles = 0, ws_mm_floats = 0;
     DevBuf ws_block, ws_pts_block, ws_sor_block;
     int64_t ws_sor_cap = 0;
+    int ws_sor_frames = 0;
 
     // accumulating cloud (pose.cpp:434 cloud_big)
     o3dr_point* cloud_big = nullptr;
@@ -83,6 +84,7 @@ struct o3dr_ctx {
     o3dr_point* cloud_alt = nullptr;  // second buffer: partition target / receive buffer of the exchange
     int64_t cloud_alt_cap = 0;
     int64_t cloud_ub = 0;          // host-side upper bound of cc_big->count
+    bool cloud_n_exact = true;     // cloud_ub IS the count (set by reads, resets and adopt; cleared by calls that append a bound)
     // running bounding box of cloud_big (min xyz, max xyz; device), kept by the frame calls so that the merge and
     // o3dr_cloud_big_bbox need no pass over the cloud; invalid after appends / transforms / exchanges
     float* cloud_box = nullptr;
@@ -251,35 +253,39 @@ static int ws_ensure(o3dr_ctx* c, int frames, int64_t cap, bool need_pts, bool g
     return O3DR_OK;
 }
 
-// buffers of the statistical outlier removal (allocated on first use: the measured configs run without it)
-static int sor_ensure(o3dr_ctx* c, int64_t cap)
+// buffers of the statistical outlier removal for `frames` clouds of at most `cap` points (allocated on first use: the
+// measured configs run without it)
+static int sor_ensure(o3dr_ctx* c, int frames, int64_t cap)
 {
     if (cap < 1) cap = 1;
-    if (cap > c->ws_sor_cap) {
-        uint32_t max_cells = (uint32_t)(cap / 2 > 1024 ? cap / 2 : 1024);
+    if (frames < 1) frames = 1;
+    if (cap > c->ws_sor_cap || frames > c->ws_sor_frames) {
+        const int64_t C = cap > c->ws_sor_cap ? cap : c->ws_sor_cap;
+        const size_t F = (size_t)(frames > c->ws_sor_frames ? frames : c->ws_sor_frames);
+        uint32_t max_cells = (uint32_t)(C / 2 > 1024 ? C / 2 : 1024);
         if (max_cells > (1u << 22)) max_cells = 1u << 22;
         size_t off = 0;
-        size_t o_xyz = off;  off += align256((size_t)cap * 16);
-        size_t o_pts = off;  off += align256((size_t)cap * 16);
-        size_t o_dist = off; off += align256((size_t)cap * 4);
-        size_t o_cs = off;   off += align256((size_t)max_cells * 4);
-        size_t o_ce = off;   off += align256((size_t)max_cells * 4);
-        size_t o_part = off; off += align256(256 * 2 * 8);
-        size_t o_geom = off; off += align256(sizeof(SorGeom));
-        size_t o_n = off;    off += 256;
+        size_t o_xyz = off;  off += align256(F * (size_t)C * 16);
+        size_t o_pts = off;  off += align256(F * (size_t)C * 16);
+        size_t o_dist = off; off += align256(F * (size_t)C * 4);
+        size_t o_cf = off;   off += align256(F * ((size_t)max_cells + 1) * 4);
+        size_t o_part = off; off += align256(F * 256 * 2 * 8);
+        size_t o_geom = off; off += align256(F * sizeof(SorGeom));
+        size_t o_n = off;    off += align256(F * 4);
         CHK(dev_ensure(c, c->ws_sor_block, off));
         char* base = (char*)c->ws_sor_block.p;
         Workspace& w = c->ws;
         w.sor_xyz = (float4*)(base + o_xyz);
         w.sor_pts = (o3dr_point*)(base + o_pts);
         w.sor_dist = (float*)(base + o_dist);
-        w.sor_cell_start = (uint32_t*)(base + o_cs);
-        w.sor_cell_end = (uint32_t*)(base + o_ce);
+        w.sor_cell_first = (uint32_t*)(base + o_cf);
         w.sor_partial = (double*)(base + o_part);
         w.sor_geom = (SorGeom*)(base + o_geom);
         w.sor_n = (uint32_t*)(base + o_n);
         w.sor_max_cells = max_cells;
-        c->ws_sor_cap = cap;
+        w.sor_cap = C;
+        c->ws_sor_cap = C;
+        c->ws_sor_frames = (int)F;
     }
     return O3DR_OK;
 }
@@ -327,7 +333,7 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (hipMalloc((void**)&c->cloud_box, 6 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->cc_big, sizeof(CloudCounters)) != hipSuccess ||
         hipMalloc((void**)&c->cc_tmp, sizeof(CloudCounters)) != hipSuccess ||
-        hipHostMalloc((void**)&c->cc_host, sizeof(CloudCounters), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->cc_host, 2 * sizeof(CloudCounters), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->n_host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->stats_dev, sizeof(SortStats)) != hipSuccess ||
         hipMalloc((void**)&c->misc_dev, 4096) != hipSuccess ||
@@ -589,12 +595,25 @@ static int stage_in(o3dr_ctx* c, DevBuf& b, const void* src, size_t bytes, int m
 }
 
 // read a CloudCounters back (synchronises)
-static int read_counters(o3dr_ctx* c, const CloudCounters* dev, CloudCounters* host)
+static int read_counters(o3dr_ctx* c, const CloudCounters* dev, CloudCounters* host, const CloudCounters* dev2 = nullptr,
+                         CloudCounters* host2 = nullptr)
 {
     HIPCHK(hipMemcpyAsync(c->cc_host, dev, sizeof(CloudCounters), hipMemcpyDeviceToHost, c->stream));
+    if (dev2) HIPCHK(hipMemcpyAsync(c->cc_host + 1, dev2, sizeof(CloudCounters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *host = *c->cc_host;
-    if (host->status & O3DR_STATUS_INTERNAL)
+    if (dev2) {
+        *host2 = c->cc_host[1];
+        if (dev2 == c->cc_big) {
+            c->cloud_ub = (int64_t)host2->count;
+            c->cloud_n_exact = true;
+        }
+    }
+    if (dev == c->cc_big) {  // every read of the cloud's counters makes the host-side bound exact
+        c->cloud_ub = (int64_t)host->count;
+        c->cloud_n_exact = true;
+    }
+    if ((host->status | (dev2 ? host2->status : 0u)) & O3DR_STATUS_INTERNAL)
         return fail(O3DR_ERR_INTERNAL, "a device-side gather guard tripped (record or point id outside its cloud); results are invalid");
     return O3DR_OK;
 }
@@ -761,8 +780,8 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
         v.stats = c->stats_dev;
         v.use_runs = 0;
         if (sor_on(c)) {  // pose_functions.cpp:1673-1686 in front of the per-frame voxel grid
-            CHK(sor_ensure(c, cap));
-            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap, v.mm_used, 1.0, c->ws.sor_pts,
+            CHK(sor_ensure(c, 1, cap));
+            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, 0, c->ws.n_valid, 1, cap, v.mm_used, 1.0, c->ws.sor_pts, 0,
                                    c->ws.sor_n);
             v.in = c->ws.sor_pts;
             v.n_dev = c->ws.sor_n;
@@ -855,7 +874,7 @@ static int put_bbox(o3dr_ctx* c, const float mn[3], const float mx[3])
 static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const float leaf[3], uint32_t min_points,
                         float z_offset, o3dr_point* out_d, int64_t* n_out, uint32_t* status,
                         const float* gmin = nullptr, const float* gmax = nullptr, bool do_sor = false,
-                        const float* box_dev = nullptr, const uint8_t* heads_in = nullptr)
+                        const float* box_dev = nullptr, const uint8_t* heads_in = nullptr, CloudCounters* big_out = nullptr)
 {
     CHK(ws_ensure(c, 1, n_in, false, c->use_runs != 0));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
@@ -888,15 +907,18 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
     v.test_corrupt = c->test_corrupt;
     c->test_corrupt = 0;
     if (do_sor) {
-        CHK(sor_ensure(c, n_in));
-        v.mm_used = launch_sor(&c->prof, c->stream, c->ws, in_d, c->ws.n_valid, n_in, mm_used, 1.0, c->ws.sor_pts, c->ws.sor_n);
+        CHK(sor_ensure(c, 1, n_in));
+        v.mm_used = launch_sor(&c->prof, c->stream, c->ws, in_d, 0, c->ws.n_valid, 1, n_in, mm_used, 1.0, c->ws.sor_pts, 0, c->ws.sor_n);
         v.in = c->ws.sor_pts;
         v.n_dev = c->ws.sor_n;
     }
     launch_voxel_grid(&c->prof, c->stream, c->ws, v);
     HIPCHK(hipGetLastError());
     CloudCounters cc;
-    CHK(read_counters(c, c->cc_tmp, &cc));
+    if (big_out)
+        CHK(read_counters(c, c->cc_tmp, &cc, c->cc_big, big_out));
+    else
+        CHK(read_counters(c, c->cc_tmp, &cc));
     *n_out = (int64_t)cc.count;
     if (status) *status = cc.status;
     return O3DR_OK;
@@ -959,11 +981,11 @@ extern "C" int o3dr_statistical_outlier_removal(o3dr_ctx* c, const o3dr_point* i
     const void* in_d;
     CHK(stage_in(c, c->st_in, in, (size_t)n_in * sizeof(o3dr_point), mem, &in_d));
     CHK(ws_ensure(c, 1, n_in, false));
-    CHK(sor_ensure(c, n_in));
+    CHK(sor_ensure(c, 1, n_in));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
     const int used = launch_points_minmax(&c->prof, c->stream, (const o3dr_point*)in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
     o3dr_point* dst = mem == O3DR_MEM_DEVICE ? out : c->ws.sor_pts;
-    launch_sor(&c->prof, c->stream, c->ws, (const o3dr_point*)in_d, c->ws.n_valid, n_in, used, 1.0, dst, c->ws.sor_n);
+    launch_sor(&c->prof, c->stream, c->ws, (const o3dr_point*)in_d, 0, c->ws.n_valid, 1, n_in, used, 1.0, dst, 0, c->ws.sor_n);
     HIPCHK(hipGetLastError());
     uint32_t m = 0;
     CHK(read_u32(c, c->ws.sor_n, &m));
@@ -1167,6 +1189,7 @@ extern "C" int o3dr_cloud_big_reset(o3dr_ctx* c)
     CHK(zero_counters(c, c->cc_big));
     CHK(cloud_box_clear(c));
     c->cloud_ub = 0;
+    c->cloud_n_exact = true;
     return O3DR_OK;
 }
 
@@ -1292,53 +1315,17 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
     float leaf[3], zo;
     uint32_t mp;
     downsample_leaf(c->params, 0, leaf, &mp, &zo);
-    if (sor_on(c) && !c->params.dont_downsample) {
-        // statistical outlier removal enabled: frames go through the single-cloud path one by one
-        CHK(ws_ensure(c, 1, cap, true));
-        CHK(sor_ensure(c, cap));
-        const void *disp_d, *bgr_d, *poses_d;
-        for (int f = 0; f < n_frames; ++f) {
-            CHK(cloud_make_room(c, cap));
-            CHK(stage_in(c, c->st_disp, disp + (int64_t)f * disp_frame_stride, (size_t)disp_frame_stride, mem, &disp_d));
-            CHK(stage_in(c, c->st_bgr, bgr + (int64_t)f * bgr_frame_stride, (size_t)bgr_frame_stride, mem, &bgr_d));
-            CHK(stage_in(c, c->st_poses, poses + 16 * (int64_t)f, 16 * sizeof(float), mem, &poses_d));
-            CHK(run_reproject_single(c, (const uint8_t*)disp_d, disp_pitch, (const uint8_t*)bgr_d, bgr_pitch, rows, cols, g,
-                                     nullptr, use_kp ? kp_d + 2 * (int64_t)kp_rel[f] : nullptr,
-                                     use_kp ? kp_rel[f + 1] - kp_rel[f] : 0, c->ws.pts, (const float*)poses_d));
-            VoxelArgs v;
-            v.in = c->ws.sor_pts;
-            v.in_fstride = 0;
-            v.n_dev = c->ws.sor_n;
-            v.frames = 1;
-            v.cap = cap;
-            v.leaf[0] = leaf[0];
-            v.leaf[1] = leaf[1];
-            v.leaf[2] = leaf[2];
-            v.min_points = mp;
-            v.z_offset = zo;
-            v.out_base = c->cloud_big;
-            v.cc = c->cc_big;
-            v.passthrough = 0;
-            v.stats = c->stats_dev;
-            v.use_runs = 0;
-            v.cloud_box = c->cloud_box_valid ? c->cloud_box : nullptr;
-            heads_for_append(c, v);
-            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap,
-                                   (int)((g.n + kEmitTile - 1) / kEmitTile) + 1, 1.0, c->ws.sor_pts, c->ws.sor_n);
-            launch_voxel_grid(&c->prof, c->stream, c->ws, v);
-            HIPCHK(hipGetLastError());
-            c->cloud_ub += cap;
-            if (mem == O3DR_MEM_HOST) HIPCHK(hipStreamSynchronize(c->stream));
-        }
-        return O3DR_OK;
-    }
+    // statistical outlier removal (pose_functions.cpp:1673-1686, in front of every per-frame voxel grid): batched like
+    // everything else - grid y = frame in all of its kernels, no host round trip per frame
+    const bool with_sor = sor_on(c) && !c->params.dont_downsample;
     int B = n_frames < c->max_batch ? n_frames : c->max_batch;
     {   // ~56 bytes of workspace per candidate point; keep a batch under 12 GiB of HBM (of 288)
-        const int64_t per_frame = 56 * cap + (1 << 20);
+        const int64_t per_frame = (with_sor ? 56 + 42 : 56) * cap + (1 << 20);
         const int64_t fit = ((int64_t)12 << 30) / per_frame;
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }
     CHK(ws_ensure(c, B, cap, true));
+    if (with_sor) CHK(sor_ensure(c, B, cap));
 
     const bool streaming = mem == O3DR_MEM_HOST;
     if (streaming) {
@@ -1389,7 +1376,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         launch_minmax_init(&c->prof, c->stream, c->ws.mm, c->ws.mm_stride, a.n_tiles, c->ws.n_kp, nb);
         // no keypoint pass in front of the grid pass and a voxel grid behind it: index and first digit histogram are
         // produced by the pass that writes the points (the keypoint pass would need them too: it keeps the two-step form)
-        const bool fused = !use_kp && !c->params.dont_downsample && a.n_tiles > 0;
+        const bool fused = !use_kp && !c->params.dont_downsample && a.n_tiles > 0 && !with_sor;
         if (use_kp)
             launch_keypoint_pass(&c->prof, c->stream, a, kp_d, 0, c->ws.pts, c->ws.n_kp, c->ws.mm, kpoff_d + f0, nb);
         if (fused)
@@ -1417,9 +1404,16 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         v.mm_used = a.n_tiles + 1;
         v.stats = c->stats_dev;
         v.use_runs = 0;
+        if (with_sor) {
+            v.mm_used = launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, cap, c->ws.n_valid, nb, cap, a.n_tiles + 1, 1.0, c->ws.sor_pts,
+                                   cap, c->ws.sor_n);
+            v.in = c->ws.sor_pts;
+            v.n_dev = c->ws.sor_n;
+        }
         launch_voxel_grid(&c->prof, c->stream, c->ws, v);
         HIPCHK(hipGetLastError());
         c->cloud_ub += (int64_t)nb * cap;
+        c->cloud_n_exact = false;
         if (streaming) HIPCHK(hipEventRecord(c->ev_done[slot], c->stream));
     }
     if (streaming) HIPCHK(hipStreamSynchronize(c->stream));  // the caller may reuse its host buffers
@@ -1450,10 +1444,17 @@ static int finalize_impl(o3dr_ctx* c, const float* gmin, const float* gmax, o3dr
     CTX_ENTER(c);
     if (!n_out) return fail(O3DR_ERR_INVALID_ARG, "n_out is NULL");
     if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    // the host knows the count exactly after a read, a reset or an adopt (the multi-GPU exchange): then the status bits
+    // accumulated in cc_big come back with the result's count, in the one round trip the merge needs anyway
     CloudCounters cc;
-    CHK(read_counters(c, c->cc_big, &cc));
+    const bool known = c->cloud_n_exact && !c->params.dont_downsample && c->cloud_ub > 0;
+    if (known) {
+        cc.count = (uint64_t)c->cloud_ub;
+        cc.status = 0;
+    } else {
+        CHK(read_counters(c, c->cc_big, &cc));
+    }
     const int64_t n = (int64_t)cc.count;
-    c->cloud_ub = n;
     if (n == 0) return O3DR_OK;
     if (n >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
     if (!out) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
@@ -1474,7 +1475,8 @@ static int finalize_impl(o3dr_ctx* c, const float* gmin, const float* gmax, o3dr
     int64_t m = 0;
     uint32_t st = 0;
     CHK(voxel_single(c, c->cloud_big, n, leaf, mp, zo, out_d, &m, &st, gmin, gmax, false,
-                     c->cloud_box_valid ? c->cloud_box : nullptr, heads_for_merge(c, leaf, zo)));
+                     c->cloud_box_valid ? c->cloud_box : nullptr, heads_for_merge(c, leaf, zo), known ? &cc : nullptr));
+    if ((int64_t)cc.count != n) return fail(O3DR_ERR_INTERNAL, "cloud_big's device count differs from the host's");
     if (mem == O3DR_MEM_HOST) {
         if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
         if (m > 0) {
@@ -1511,11 +1513,23 @@ extern "C" int o3dr_cloud_big_view(o3dr_ctx* c, void** ptr, int64_t* n)
 {
     CTX_ENTER(c);
     if (!ptr || !n) return fail(O3DR_ERR_INVALID_ARG, "ptr / n is NULL");
-    CloudCounters cc;
-    CHK(read_counters(c, c->cc_big, &cc));
-    c->cloud_ub = (int64_t)cc.count;
+    if (!c->cloud_n_exact) {  // (no round trip when the host already knows the size: reads, resets, adopt, assume_size)
+        CloudCounters cc;
+        CHK(read_counters(c, c->cc_big, &cc));
+    }
     *ptr = c->cloud_big;
-    *n = (int64_t)cc.count;
+    *n = c->cloud_ub;
+    return O3DR_OK;
+}
+// The caller learnt cloud_big's exact size by other means (its own header from o3dr_cloud_big_header_dev, read back
+// with the all-to-all's sizes): later calls then need no round trip for it.  A wrong value is caught by the merge
+// (O3DR_ERR_INTERNAL), never used to address memory beyond the cloud's capacity.
+extern "C" int o3dr_cloud_big_assume_size(o3dr_ctx* c, int64_t n_points)
+{
+    CTX_ENTER(c);
+    if (n_points < 0 || n_points > c->cloud_ub) return fail(O3DR_ERR_INVALID_ARG, "size above what the calls so far can have produced");
+    c->cloud_ub = n_points;
+    c->cloud_n_exact = true;
     return O3DR_OK;
 }
 extern "C" int o3dr_cloud_big_recv_buffer(o3dr_ctx* c, int64_t n_points, void** ptr)
@@ -1531,18 +1545,74 @@ extern "C" int o3dr_cloud_big_adopt(o3dr_ctx* c, int64_t n_points)
     CTX_ENTER(c);
     if (n_points < 0 || n_points > c->cloud_alt_cap) return fail(O3DR_ERR_INVALID_ARG, "more points than the receive buffer holds");
     if (n_points >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
-    CloudCounters* h = c->cc_host;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    h->count = (uint64_t)n_points;
-    h->status = 0;
-    h->pad = 0;
-    // keep the status bits accumulated so far: read-modify-write of the count only
-    HIPCHK(hipMemcpyAsync(&c->cc_big->count, &h->count, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // stream-ordered, no host round trip: the count is set by a one-thread kernel (the status bits accumulated so far
+    // are kept); what filled the receive buffer must be ordered before this stream's next work by the caller
+    launch_set_cloud_count(c->stream, c->cc_big, (uint64_t)n_points);
+    HIPCHK(hipGetLastError());
     swap_clouds(c);
     c->cloud_box_valid = false;
     c->cloud_heads_valid = false;
     c->cloud_ub = n_points;
+    c->cloud_n_exact = true;
+    return O3DR_OK;
+}
+
+// ---- the exchange's small data on the device: header (box + count) and slice counts without a host round trip ----------
+extern "C" int o3dr_cloud_big_header_dev(o3dr_ctx* c, void* hdr_dev)
+{
+    CTX_ENTER(c);
+    if (!hdr_dev) return fail(O3DR_ERR_INVALID_ARG, "hdr_dev is NULL");
+    const float* box = c->cloud_box;
+    if (!c->cloud_box_valid) {
+        float* tmp = (float*)c->misc_dev;
+        if (c->cloud_ub == 0 || !c->cloud_big) {
+            static const float empty[6] = {__builtin_inff(), __builtin_inff(), __builtin_inff(),
+                                           -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            HIPCHK(hipMemcpyAsync(tmp, empty, sizeof empty, hipMemcpyHostToDevice, c->stream));
+        } else {  // appends / transforms / exchanges dropped the running box: one pass over the cloud, sized by the bound
+            if (c->cloud_ub >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+            CHK(ws_ensure(c, 1, c->cloud_ub, false));
+            launch_count_from_cc(c->stream, c->cc_big, c->ws.n_valid);
+            const int used = launch_points_minmax(&c->prof, c->stream, c->cloud_big, 0, c->ws.n_valid, 1, c->cloud_ub, c->ws.mm_stride, c->ws.mm);
+            launch_bbox(&c->prof, c->stream, c->ws.mm, used, tmp);
+        }
+        box = tmp;
+    }
+    launch_pack_header(c->stream, box, c->cc_big, hdr_dev);
+    HIPCHK(hipGetLastError());
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_partition_dev(o3dr_ctx* c, const void* hdrs_dev, int32_t n_hdrs, int32_t n_parts, int64_t* counts_dev)
+{
+    CTX_ENTER(c);
+    if (!hdrs_dev || !counts_dev || n_hdrs < 1 || n_parts < 1 || n_parts > kMaxRadix)
+        return fail(O3DR_ERR_INVALID_ARG, "bad arguments (1 <= n_parts <= 128)");
+    HIPCHK(hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * ((size_t)n_parts + 1), c->stream));
+    const int64_t ub = c->cloud_ub;  // kernels take the count from the device; the bound sizes grids and buffers
+    if (ub == 0 || !c->cloud_big) return O3DR_OK;
+    if (ub >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+    CHK(ws_ensure(c, 1, ub, false));
+    CHK(alt_reserve(c, ub));
+    o3dr_point* nb = c->cloud_alt;
+    launch_count_from_cc(c->stream, c->cc_big, c->ws.n_valid);
+    float leaf[3], zo;
+    uint32_t mp;
+    downsample_leaf(c->params, 1, leaf, &mp, &zo);
+    VoxelArgs v;
+    memset(&v, 0, sizeof v);
+    v.in = c->cloud_big;
+    v.n_dev = c->ws.n_valid;
+    v.frames = 1;
+    v.cap = ub;
+    v.leaf[0] = leaf[0];
+    v.leaf[1] = leaf[1];
+    v.leaf[2] = leaf[2];
+    v.z_offset = zo;
+    launch_partition(&c->prof, c->stream, c->ws, v, n_parts, nb, (uint64_t*)counts_dev, (uint32_t*)(counts_dev + n_parts), hdrs_dev, n_hdrs);
+    if (hipGetLastError() != hipSuccess) return fail(O3DR_ERR_HIP, "partition launch failed");
+    swap_clouds(c);  // the partitioned copy becomes cloud_big; the old buffer is kept as the alternate
+    c->cloud_heads_valid = false;
     return O3DR_OK;
 }
 

@@ -65,6 +65,7 @@ struct VoxelGeom {
 
 // ---- statistical outlier removal (A3b): search grid + threshold, written by k_sor_plan / k_sor_threshold ----
 constexpr int kSorMeanK = 50;  // sor0.setMeanK(50), pose_functions.cpp:1681
+constexpr double kSorCellPoints = 16.0;  // points per column of the search grid, on average
 struct SorGeom {
     float mnx, mny, inv_h, h;
     int32_t gx, gy;
@@ -117,16 +118,16 @@ struct Workspace {
     uint32_t* seg_cnt = nullptr;   // frames*n_seg_tiles (run heads per tile, then kept runs per tile)
     uint8_t* head_bits = nullptr;  // frames*n_seg_tiles*256: run-head flags, 4 records per byte (k_run_heads -> k_run_starts)
     uint32_t* scan_partial = nullptr;  // chunk sums of the multi-workgroup scan
-    // statistical outlier removal (single-cloud path)
-    SorGeom* sor_geom = nullptr;
-    float4* sor_xyz = nullptr;          // cap      coordinates in cell order
-    float* sor_dist = nullptr;          // cap      mean neighbour distance per point
-    uint32_t* sor_cell_start = nullptr; // sor_max_cells
-    uint32_t* sor_cell_end = nullptr;
+    // statistical outlier removal (sor_frames clouds of at most sor_cap points)
+    SorGeom* sor_geom = nullptr;        // frames
+    float4* sor_xyz = nullptr;          // frames*cap      coordinates in cell order
+    float* sor_dist = nullptr;          // frames*cap      mean neighbour distance per point
+    uint32_t* sor_cell_first = nullptr; // frames*(sor_max_cells+1): points in cells below c (exclusive scan of the populations)
     uint32_t sor_max_cells = 0;
-    double* sor_partial = nullptr;      // 256*2
-    o3dr_point* sor_pts = nullptr;      // cap      inliers
-    uint32_t* sor_n = nullptr;          // 1        inlier count
+    double* sor_partial = nullptr;      // frames*256*2
+    o3dr_point* sor_pts = nullptr;      // frames*cap      inliers
+    uint32_t* sor_n = nullptr;          // frames          inlier count
+    int64_t sor_cap = 0;                // points per frame the arrays above are laid out for
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
     uint32_t* run_start = nullptr; // frames*(cap+1)  first point of every group run (grouped path), + sentinel
     uint32_t* grp_cnt = nullptr;   // grp_slots/64 + 2: output voxels per group -> exclusive prefix (grouped path, frames == 1)
@@ -230,9 +231,17 @@ int bilateral_tile_width(int radius);
 void launch_disp_variance(Profiler* pf, hipStream_t s, const uint8_t* disp, int64_t pitch, int64_t fstride, int rows, int cols,
                           int frames, int bb, int cs, double min_disp, unsigned long long* hist, double* var_out);
 void launch_bbox(Profiler* pf, hipStream_t s, const float* mm, int used, float* out6);
-int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, const uint32_t* n_dev, int64_t cap,
-               int mm_used, double stddev_mul, o3dr_point* out, uint32_t* n_out_dev);
+// statistical outlier removal of `frames` clouds (cloud f = in + f*in_fstride, n_dev[f] points, bounding boxes in ws.mm
+// slots [0, mm_used) of frame f): inliers -> out + f*out_fstride in input order, counts -> n_out_dev[f], their bounding
+// boxes -> ws.mm slots [0, returned value) of frame f.  The sort buffers of ws (keys/vals/hist/geom) are used.
+int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, int64_t in_fstride, const uint32_t* n_dev,
+               int frames, int64_t cap, int mm_used, double stddev_mul, o3dr_point* out, int64_t out_fstride,
+               uint32_t* n_out_dev);
 void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
-                      uint64_t* counts_dev, uint32_t* overflow_dev);
+                      uint64_t* counts_dev, uint32_t* overflow_dev, const void* hdrs_dev = nullptr, int n_hdrs = 0);
+// the exchange's small data, kept on the device (kernels/multigpu.inc)
+void launch_pack_header(hipStream_t s, const float* box6_dev, const CloudCounters* cc, void* hdr32_dev);
+void launch_count_from_cc(hipStream_t s, const CloudCounters* cc, uint32_t* n_dev);
+void launch_set_cloud_count(hipStream_t s, CloudCounters* cc, uint64_t n);
 
 }  // namespace o3dr

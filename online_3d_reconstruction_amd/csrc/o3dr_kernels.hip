@@ -366,13 +366,22 @@ void launch_bbox(Profiler* pf, hipStream_t s, const float* mm, int used, float* 
 // Stable partition of `in` (n points, count also in v.n_dev[0]) by index slice of the voxel grid whose
 // bounding box sits in ws.mm slot 0.  out = reordered points, counts_dev[n_parts], overflow_dev = 1 when
 // PCL's overflow guard fires for that box (then out = in and every count is 0).
+void launch_pack_header(hipStream_t s, const float* box6_dev, const CloudCounters* cc, void* hdr32_dev)
+{
+    k_pack_header<<<1, 1, 0, s>>>(box6_dev, cc, reinterpret_cast<CloudHeader*>(hdr32_dev));
+}
+void launch_count_from_cc(hipStream_t s, const CloudCounters* cc, uint32_t* n_dev) { k_count_from_cc<<<1, 1, 0, s>>>(cc, n_dev); }
+void launch_set_cloud_count(hipStream_t s, CloudCounters* cc, uint64_t n) { k_set_cloud_count<<<1, 1, 0, s>>>(cc, n); }
+
+// hdrs_dev (optional): the box in ws.mm slot 0 is first folded from n_hdrs 32-byte rank headers in HBM
 void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
-                      uint64_t* counts_dev, uint32_t* overflow_dev)
+                      uint64_t* counts_dev, uint32_t* overflow_dev, const void* hdrs_dev, int n_hdrs)
 {
     const int64_t cap = v.cap;
     const int n_sort_tiles = cdiv64(cap, kSortTile);
     const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
     ProfScope ps(pf, O3DR_K_OTHER, s);
+    if (hdrs_dev) k_fold_headers<<<1, 1, 0, s>>>(reinterpret_cast<const CloudHeader*>(hdrs_dev), n_hdrs, ws.mm);
     k_voxel_geom<<<1, 256, 0, s>>>(ws.mm, ws.mm_stride, 1, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset, ws.geom);
     // count per (part, tile), scan, move the points (two reads and one write of the cloud); n_parts <= kMaxRadix
     k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
@@ -382,36 +391,43 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
     k_part_counts_scanned<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.hist, ws.geom, n_parts, n_sort_tiles, counts_dev, overflow_dev);
 }
 
-// Statistical outlier removal of ONE cloud (`in`, count in n_dev[0], at most cap points, bounding boxes in
-// ws.mm slots [0, mm_used)).  Kept points -> out (same order), their count -> n_out_dev[0], their
-// bounding boxes -> ws.mm slots [0, returned value).
-int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, const uint32_t* n_dev, int64_t cap,
-               int mm_used, double stddev_mul, o3dr_point* out, uint32_t* n_out_dev)
+// Statistical outlier removal of a batch of clouds (see o3dr_device.h).  ws.sor_* are laid out for ws.sor_cap points
+// per frame; cap (<= ws.sor_cap) sizes the grids.
+int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, int64_t in_fstride, const uint32_t* n_dev,
+               int frames, int64_t cap, int mm_used, double stddev_mul, o3dr_point* out, int64_t out_fstride,
+               uint32_t* n_out_dev)
 {
     ProfScope ps(pf, O3DR_K_OTHER, s);
+    const int F = frames;
     const int n_sort_tiles = cdiv64(cap, kSortTile);
     const int64_t hist_row = (int64_t)kMaxRadix * n_sort_tiles;
+    const size_t tm_lds = (size_t)n_sort_tiles * (kMaxRadix + 1) * sizeof(uint32_t);
+    const int tm = tm_lds <= 48 * 1024 ? 1 : 0;
     const int n_tiles = cdiv64(cap, 1024);
-    k_sor_plan<<<1, 256, 0, s>>>(ws.mm, mm_used, n_dev, ws.sor_max_cells, ws.sor_geom, ws.geom);
-    (void)hipMemsetAsync(ws.sor_cell_start, 0, (size_t)ws.sor_max_cells * 4, s);
-    (void)hipMemsetAsync(ws.sor_cell_end, 0, (size_t)ws.sor_max_cells * 4, s);
-    k_sor_cells<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.sor_geom, ws.keys[0]);
+    const int64_t cell_stride = (int64_t)ws.sor_max_cells + 1;
+    k_sor_plan<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, mm_used, n_dev, ws.sor_max_cells, ws.sor_geom, ws.geom);
+    (void)hipMemsetAsync(ws.sor_cell_first, 0, (size_t)F * (size_t)cell_stride * 4, s);
+    k_sor_cells<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(in, in_fstride, ws.sor_geom, cap, ws.keys[0], cell_stride, ws.sor_cell_first);
+    launch_scan(s, ws.sor_cell_first, cell_stride, cell_stride, F, nullptr, nullptr, ws.scan_partial);
     for (int pass = 0; pass < kMaxPasses; ++pass) {
-        k_radix_hist<<<dim3(n_sort_tiles, 1), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part, 0);
-        launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
-        k_radix_scatter_lane<<<dim3(xcd_grid((int64_t)n_sort_tiles * kScatParts), 1), kScatThreads, 0, s>>>(
-            ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part, 0);
+        k_radix_hist<<<dim3(n_sort_tiles, F), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist,
+                                                                    ws.hist_part, tm);
+        if (tm)
+            k_scan_hist_tm<<<F, 1024, tm_lds, s>>>(ws.hist, ws.geom, pass, n_sort_tiles);
+        else
+            launch_scan(s, ws.hist, hist_row, hist_row, F, nullptr, nullptr, ws.scan_partial, ws.geom, pass, n_sort_tiles);
+        k_radix_scatter_lane<<<dim3(xcd_grid((int64_t)n_sort_tiles * kScatParts), F), kScatThreads, 0, s>>>(
+            ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part, tm);
     }
-    k_sor_cell_table<<<cdiv64(cap, 256), 256, 0, s>>>(in, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom,
-                                                     ws.sor_xyz, ws.sor_cell_start, ws.sor_cell_end);
-    k_sor_knn<<<cdiv64(cap, kSorThreads), kSorThreads, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_start,
-                                                              ws.sor_cell_end, ws.sor_geom, ws.sor_dist);
-    constexpr int kStatBlocks = 256;
-    k_sor_partial<<<kStatBlocks, 256, 0, s>>>(ws.sor_dist, ws.sor_geom, ws.sor_partial);
-    k_sor_threshold<<<1, 1, 0, s>>>(ws.sor_partial, kStatBlocks, stddev_mul, ws.sor_geom);
-    k_sor_count<<<n_tiles, 256, 0, s>>>(ws.sor_dist, ws.sor_geom, ws.tile_cnt);
-    launch_scan(s, ws.tile_cnt, n_tiles, n_tiles, 1, n_out_dev, nullptr, ws.scan_partial);
-    k_sor_emit<<<n_tiles, 256, 0, s>>>(in, ws.sor_dist, ws.sor_geom, ws.tile_cnt, out, ws.mm_stride, ws.mm);
+    k_sor_gather<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(in, in_fstride, ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom, cap, ws.sor_xyz);
+    k_sor_knn<<<dim3(cdiv64(cap, kWave), F), kWave, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_first, cell_stride,
+                                                           ws.sor_geom, cap, ws.sor_dist);
+    k_sor_partial<<<dim3(kSorStatBlocks, F), 256, 0, s>>>(ws.sor_dist, cap, ws.sor_geom, ws.sor_partial);
+    k_sor_threshold<<<cdiv64(F, 64), 64, 0, s>>>(ws.sor_partial, stddev_mul, ws.sor_geom, F);
+    k_sor_count<<<dim3(n_tiles, F), 256, 0, s>>>(ws.sor_dist, cap, ws.sor_geom, n_tiles, ws.tile_cnt);
+    launch_scan(s, ws.tile_cnt, n_tiles, n_tiles, F, n_out_dev, nullptr, ws.scan_partial);
+    k_sor_emit<<<dim3(n_tiles, F), 256, 0, s>>>(in, in_fstride, ws.sor_dist, cap, ws.sor_geom, n_tiles, ws.tile_cnt, out, out_fstride,
+                                                ws.mm_stride, ws.mm);
     return n_tiles;
 }
 

@@ -61,65 +61,155 @@ def _all_to_all_points(send, send_counts, group=None):
     return recv, recv_counts
 
 
+# what the last merge_partitioned of this process did: collectives issued and host round trips (stream drains / blocking
+# read-backs) before the final gather — the figures DESIGN.md section 5 quotes; tests assert them
+last_stats = {}
+
+
+def _header_tensor(ctx, cdev, dev_path):
+    """this rank's 32-byte header {min xyz, max xyz (f32), count (i64)} as a uint8 tensor on the collective's device"""
+    import numpy as np
+    if dev_path:
+        return ctx.cloudBigHeaderDev()  # stays in HBM: no round trip
+    mn, mx, n_local = ctx.cloudBigBBox()
+    raw = np.concatenate([np.asarray(mn, np.float32), np.asarray(mx, np.float32)]).tobytes() + np.int64(n_local).tobytes()
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(cdev)
+
+
+def _parse_headers(raw, world):
+    """[world*32] uint8 (host) -> (gmin, gmax, per-rank counts)"""
+    import numpy as np
+    b = raw.reshape(world, 32)
+    boxes = np.ascontiguousarray(b[:, :24]).view(np.float32).reshape(world, 6)
+    counts = np.ascontiguousarray(b[:, 24:]).view(np.int64).reshape(world)
+    live = counts > 0
+    if not live.any():
+        return np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32), counts
+    return boxes[live, 0:3].min(axis=0).astype(np.float32), boxes[live, 3:6].max(axis=0).astype(np.float32), counts
+
+
 def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=None):
     """The reference's final merge (pose.cpp:530) over frames sharded across ranks, without replicating it:
 
-      1. all-reduce (min/max) of the ranks' cloud_big bounding boxes -> the box PCL would see;
+      1. all-gather of the ranks' 32-byte headers (bounding box + size of cloud_big) -> the box PCL would see;
       2. every rank stably reorders its cloud by index slice of the combined grid over that box
          (slice r = the r-th of `world` equal ranges of the linear voxel index);
-      3. one all-to-all (RCCL over xGMI: every peer pair uses its own link) moves slice r to rank r;
-         segments arrive in source-rank order = global frame order;
-      4. every rank merges its slice with the grid over the global box;
+      3. all-gather of the slice-count vectors, ONE host read-back (headers + count matrix), then one all-to-all
+         (RCCL over xGMI: every peer pair uses its own link) moves slice r to rank r; segments arrive in
+         source-rank order = global frame order;
+      4. every rank merges its slice with the grid over the global box (second and last host round trip: the
+         merged slice's size);
       5. all-gather of the (small) merged slices; rank order = ascending voxel index.
 
+    With a GPU context (cloudBigHeaderDev / cloudBigPartitionDev) steps 1-3 keep their data in HBM and every call is
+    stream-ordered: the host waits once for the count matrix and once for the merged size.  Contexts without those
+    methods (CPU stand-ins in the gloo tests) and rehearsals with `comm_device` (collectives on host copies) run the
+    same protocol on host values.
+
     Returns (merged [M,4] int32 tensor or this rank's slice if gather_result is False, total points merged).
-    Bit-identical to a single-GPU run over all frames.  `comm_device` (rehearsal with the gloo backend
-    on one GPU): run the collectives on copies on that device instead of `device`."""
+    Bit-identical to a single-GPU run over all frames."""
     import numpy as np
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     cdev = comm_device if comm_device is not None else device
-    mn, mx, n_local = ctx.cloudBigBBox()
-    # one small all-gather carries every rank's box and count (instead of two all-reduces): 6 floats + the count
-    # split into two 24-bit halves, exact in fp32
-    mine_hdr = torch.tensor(np.concatenate([mn, mx, [float(n_local & 0xFFFFFF), float(n_local >> 24)]]), dtype=torch.float32,
-                            device=cdev)
-    hdr = torch.empty(world * 8, dtype=torch.float32, device=cdev)  # (flat: gloo wants the concatenated shape)
-    dist.all_gather_into_tensor(hdr, mine_hdr, group=group)
-    hdr = hdr.cpu().numpy().reshape(world, 8)
-    gmin = hdr[:, 0:3].min(axis=0).astype(np.float32)  # empty ranks contribute (+inf, -inf)
-    gmax = hdr[:, 3:6].max(axis=0).astype(np.float32)
-    total = int(sum(int(h[6]) + (int(h[7]) << 24) for h in hdr))
+    on_gpu = torch.device(device).type == "cuda"
+    dev_path = comm_device is None and hasattr(ctx, "cloudBigPartitionDev")
+    stats = {"collectives": 0, "host_syncs_before_final_gather": 0, "device_resident": bool(dev_path)}
+    # Stream order: the library works on the context's stream, torch's collectives are ordered against torch's current
+    # stream.  When the two are the same stream (bench.py hands the context torch's), nothing else is needed; else the
+    # host drains one for the other (counted below).
+    same_stream = (not on_gpu) or (getattr(ctx, "stream_raw", 0) != 0 and
+                                   ctx.stream_raw == torch.cuda.current_stream(device).cuda_stream)
+
+    def lib_to_torch():  # library work issued so far must precede the next collective
+        if dev_path and not same_stream:
+            ctx.synchronize()
+            stats["host_syncs_before_final_gather"] += 1
+
+    def torch_to_lib():  # ... and the collective must precede the library's next work
+        if on_gpu and comm_device is None and not same_stream:
+            torch.cuda.current_stream(device).synchronize()
+            stats["host_syncs_before_final_gather"] += 1
+
+    # 1. headers
+    mine_hdr = _header_tensor(ctx, cdev, dev_path)
+    if not dev_path:
+        stats["host_syncs_before_final_gather"] += 1  # (host values: the box and count were read back)
+    lib_to_torch()
+    hdrs = torch.empty(world * 32, dtype=torch.uint8, device=cdev)
+    dist.all_gather_into_tensor(hdrs, mine_hdr, group=group)
+    stats["collectives"] += 1
+    # 2. partition (+ status word)
+    if dev_path:
+        torch_to_lib()
+        row = ctx.cloudBigPartitionDev(hdrs, world)       # int64 [world + 1] in HBM, asynchronous
+        lib_to_torch()
+    else:
+        gmin, gmax, hcounts = _parse_headers(hdrs.cpu().numpy(), world)
+        if int(hcounts.sum()) == 0:
+            last_stats.clear()
+            last_stats.update(stats)
+            return torch.empty((0, 4), dtype=torch.int32, device=device), 0
+        counts, status = ctx.cloudBigPartition(gmin, gmax, world)
+        stats["host_syncs_before_final_gather"] += 1
+        row = torch.tensor(list(counts) + [int(status)], dtype=torch.int64, device=cdev)
+    # 3. count matrix, the one read-back, the all-to-all
+    matrix = torch.empty(world * (world + 1), dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(matrix, row, group=group)   # row s = what rank s sends to everybody (+ its status)
+    stats["collectives"] += 1
+    both = torch.cat([hdrs.view(torch.int64), matrix]).cpu().numpy()  # headers + matrix: ONE blocking copy
+    hdrs_h = both[: world * 4].view(np.uint8)
+    matrix_h = both[world * 4:].reshape(world, world + 1)
+    if dev_path:
+        stats["host_syncs_before_final_gather"] += 1
+    gmin, gmax, hcounts = _parse_headers(hdrs_h, world)
+    total = int(hcounts.sum())
+    n_local = int(hcounts[rank])
     if total == 0:
+        last_stats.clear()
+        last_stats.update(stats)
         return torch.empty((0, 4), dtype=torch.int32, device=device), 0
-    counts, status = ctx.cloudBigPartition(gmin, gmax, world)
-    if status & 1:  # PCL's overflow guard on the global box: the merge returns its input unchanged
+    counts = [int(v) for v in matrix_h[rank, :world]]
+    overflow = bool((matrix_h[:, world] & 1).any())         # (the same global box on every rank: all agree)
+    if overflow:  # PCL's overflow guard on the global box: the merge returns its input unchanged
         counts = [0] * world
         counts[rank] = n_local  # everything stays where it is; rank order is already global order
-    # Streams: cloudBigPartition returns after its own stream has drained (it reads the counts back), so the
-    # collective below may run on any stream; it is drained in turn before the library adopts what it received.
+        recv_counts = list(counts)
+    else:
+        recv_counts = [int(v) for v in matrix_h[:, rank]]
+    n_recv = sum(recv_counts)
     zero_copy = comm_device is None and hasattr(ctx, "cloudBigView")
     if zero_copy:
         # send straight out of cloud_big, receive straight into the library's second cloud buffer
+        if hasattr(ctx, "cloudBigAssumeSize"):
+            ctx.cloudBigAssumeSize(n_local)                 # (its own header told the host: no round trip for the view)
         send = ctx.cloudBigView()
-        sc = torch.tensor(counts, dtype=torch.int64, device=device)
-        allc = torch.empty(world * world, dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(allc, sc, group=group)   # row s = what rank s sends to everybody
-        recv_counts = [int(v) for v in allc.view(world, world)[:, rank].tolist()]
-        n_recv = sum(recv_counts)
         recv = ctx.cloudBigRecvBuffer(n_recv)
+        lib_to_torch()
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
-        if torch.device(device).type == "cuda":
-            torch.cuda.current_stream(device).synchronize()
-        ctx.cloudBigAdopt(n_recv)
+        stats["collectives"] += 1
+        torch_to_lib()
+        ctx.cloudBigAdopt(n_recv)                           # stream-ordered
     else:
         send = ctx.cloudBigRead(device=device).to(cdev)
-        recv, _ = _all_to_all_points(send, counts, group)
+        recv = torch.empty((n_recv, 4), dtype=torch.int32, device=cdev)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
+        stats["collectives"] += 1
         ctx.cloudBigReset()
         if recv.shape[0]:
             ctx.cloudBigAppend(recv.to(device))
-    mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax)
+    # 4. local merge of the slice (the round trip for its size is inside)
+    if dev_path:
+        mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax, n_hint=n_recv)
+    else:
+        mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax)
+    stats["host_syncs_before_final_gather"] += 1
+    last_stats.clear()
+    last_stats.update(stats)
     if not gather_result:
         return mine, total
+    # 5. final gather (sizes, then the padded slices)
+    lib_to_torch()
     shards, _ = all_gather_points(mine.to(cdev), group)
+    last_stats["collectives"] += 2
     return torch.cat(shards).to(device), total

@@ -144,6 +144,31 @@ class CpuCtxZeroCopy(CpuCtx):
         self.cloud = self._recv[: int(n_points)].numpy().view(self.orc.POINT).reshape(-1).copy()
 
 
+class CpuCtxDev(CpuCtxZeroCopy):
+    """+ the device-resident small data of the real context (o3dr_cloud_big_header_dev / _partition_dev / _assume_size):
+    the header and the slice counts are tensors the collectives take as they are; finalize takes the size it is told"""
+
+    def cloudBigHeaderDev(self):
+        mn, mx, n = self.cloudBigBBox()
+        raw = np.concatenate([mn, mx]).astype(np.float32).tobytes() + np.int64(n).tobytes()
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+
+    def cloudBigPartitionDev(self, hdrs, n_parts):
+        from online_3d_reconstruction_amd.dist import _parse_headers
+        gmin, gmax, counts = _parse_headers(hdrs.numpy(), hdrs.numel() // 32)
+        if int(counts.sum()) == 0 or len(self.cloud) == 0:
+            return torch.zeros(n_parts + 1, dtype=torch.int64)
+        cnt, st = self.cloudBigPartition(gmin, gmax, n_parts)
+        return torch.tensor(list(cnt) + [st], dtype=torch.int64)
+
+    def cloudBigAssumeSize(self, n):
+        assert n == len(self.cloud)
+
+    def finalize(self, device=None, gmin=None, gmax=None, n_hint=None):
+        assert n_hint is None or n_hint == len(self.cloud)
+        return super().finalize(device, gmin, gmax)
+
+
 def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
     import sys
     sys.path.insert(0, ROOT)
@@ -157,12 +182,17 @@ def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
     F_total, rows, cols, jump, vs = 7, 240, 400, 2, 0.05
     Q = synth.camera_Q(rows, cols)
     a, b = o3dist.shard_range(F_total, rank, world)
-    ctx = (CpuCtxZeroCopy if zero_copy else CpuCtx)(orc, vs)
+    ctx = {False: CpuCtx, True: CpuCtxZeroCopy, "dev": CpuCtxDev}[zero_copy](orc, vs)
     for i in range(a, b):
         d, c = synth.make_frame(i, rows, cols)
         ctx.cloud = np.concatenate([ctx.cloud, orc.create_and_transform_pt_cloud(d, c, Q, synth.make_pose(i), vs, jump_pixels=jump)[0]])
     n_before = len(ctx.cloud)
     merged, total = o3dist.merge_partitioned(ctx, torch.device("cpu"))
+    st = o3dist.last_stats
+    # 5 collectives in all (headers, slice counts, all-to-all, merged sizes, merged slices); with the device-resident
+    # small data the host waits twice before the final gather: for the count matrix and for the merged slice's size
+    assert st["collectives"] == 5 and st["device_resident"] == (zero_copy == "dev")
+    assert st["host_syncs_before_final_gather"] == (2 if zero_copy == "dev" else 3), st
     if zero_copy:  # counts matrix -> receive counts: what arrived is this rank's slice of everybody's cloud
         sent = torch.tensor([n_before], dtype=torch.int64)
         got = torch.tensor([len(ctx.cloud)], dtype=torch.int64)
@@ -177,11 +207,12 @@ def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("zero_copy", [False, True])
+@pytest.mark.parametrize("zero_copy", [False, True, "dev"])
 def test_partitioned_merge_equals_single_process(tmp_path, orc, zero_copy):
     """3 ranks, 7 frames: slices exchanged all-to-all, merged locally, gathered == one-process merge; with the copying
     exchange (what a rehearsal over gloo uses) and with the zero-copy one the GPU path takes (send view, library-owned
-    receive buffer, adopt)"""
+    receive buffer, adopt), and with the header and slice counts as device-resident tensors ("dev": the protocol of the
+    real context, two host waits before the final gather)"""
     from online_3d_reconstruction_amd import synth
     world = 3
     mp.spawn(_worker_partitioned, args=(world, _free_port(), str(tmp_path), zero_copy), nprocs=world, join=True)

@@ -350,17 +350,32 @@ def _virtual_rank_merge(Qs, disp, bgr, poses, prm, world):
         ref = one.finalize()
     ctxs = [o3dr.Context(0, Q=Qs, params=prm) for _ in range(world)]
     try:
-        boxes = []
+        import torch
+        boxes, hdrs = [], []
         for r, c in enumerate(ctxs):
             a, b = shard_range(F, r, world)
             if b > a:
                 c.accumulateFrames(disp[a:b], bgr[a:b], poses[a:b])
+            hdrs.append(c.cloudBigHeaderDev())  # (before anything reads the size back: the bound sizes the grids)
             boxes.append(c.cloudBigBBox())
-        gmin = np.min([b[0] for b in boxes], axis=0)
-        gmax = np.max([b[1] for b in boxes], axis=0)
+        gmin = np.min([b[0] for b in boxes if b[2] > 0], axis=0)
+        gmax = np.max([b[1] for b in boxes if b[2] > 0], axis=0)
+        torch.cuda.synchronize()
+        all_hdrs = torch.cat(hdrs)  # what the all-gather of the headers leaves on every rank
+        hb = all_hdrs.cpu().numpy().reshape(world, 32)
+        for r, b in enumerate(boxes):  # the device-side header = the host-side box and count
+            assert np.array_equal(hb[r, 24:].view(np.int64), [b[2]])
+            if b[2] > 0:
+                assert np.array_equal(hb[r, :24].view(np.float32), np.concatenate([b[0], b[1]]))
         sends, counts = [], []
-        for c in ctxs:
-            cnt, st = c.cloudBigPartition(gmin, gmax, world)
+        for r, c in enumerate(ctxs):
+            if r % 2 == 0:  # the two forms of the partition must agree: host box in, counts out / headers in HBM, counts in HBM
+                cnt, st = c.cloudBigPartition(gmin, gmax, world)
+            else:
+                row = c.cloudBigPartitionDev(all_hdrs, world)
+                c.synchronize()
+                row = [int(v) for v in row.cpu().tolist()]
+                cnt, st = row[:world], row[world]
             assert st == 0
             pts = c.cloudBigRead()
             assert sum(cnt) == len(pts)
@@ -556,6 +571,21 @@ def test_zero_copy_exchange_single_rank_rccl(orc):
             assert_points_equal(points_from_torch(merged), ref, "zero-copy exchange, one rank")
             # cloud_big survived the exchange intact (same points, partition order = original for one slice)
             assert c.cloudBigSize()[0] == total
+            # the protocol as bench.py runs it (the context on torch's stream): header and slice counts stay in HBM,
+            # the host waits once for the count matrix and once for the merged size; straight after frame calls, whose
+            # size the host only knows as a bound
+            c.cloudBigReset()
+            c.accumulateFrames(disp, bgr, poses)
+            merged, total2 = o3dist.merge_partitioned(c, dev)
+            assert total2 == total
+            assert_points_equal(points_from_torch(merged), ref, "device-resident exchange after frame calls")
+            st = dict(o3dist.last_stats)
+            assert st["device_resident"] and st["collectives"] == 5 and st["host_syncs_before_final_gather"] == 2, st
+        with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=2, voxel_size=0.05)) as c:  # the context's own stream
+            c.accumulateFrames(disp, bgr, poses)
+            merged, _ = o3dist.merge_partitioned(c, dev)
+            assert_points_equal(points_from_torch(merged), ref, "exchange with the context on its own stream")
+            assert o3dist.last_stats["host_syncs_before_final_gather"] > 2  # (ordered by host waits instead)
     finally:
         dist.destroy_process_group()
 
