@@ -65,7 +65,10 @@ struct VoxelGeom {
 
 // ---- statistical outlier removal (A3b): search grid + threshold, written by k_sor_plan / k_sor_threshold ----
 constexpr int kSorMeanK = 50;  // sor0.setMeanK(50), pose_functions.cpp:1681
-constexpr double kSorCellPoints = 16.0;  // points per column of the search grid, on average
+#ifndef O3DR_SOR_CELLPTS
+#define O3DR_SOR_CELLPTS 30.0
+#endif
+constexpr double kSorCellPoints = O3DR_SOR_CELLPTS;  // points per column of the search grid, on average
 struct SorGeom {
     float mnx, mny, inv_h, h;
     int32_t gx, gy;
