@@ -211,7 +211,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    stream = torch.cuda.current_stream()
+    # N > 1: the library and torch's collectives work on ONE explicit stream, so that the exchange needs no host waits to
+    # order them (the NULL stream handle would mean "the context's own stream" to o3dr_ctx_set_stream)
+    stream = torch.cuda.Stream(device=dev) if world > 1 else torch.cuda.current_stream()
+    if world > 1:
+        torch.cuda.set_stream(stream)
 
     ctx = o3dr.Context(local_rank, Q=Q, params=o3dr.Params(jump_pixels=args.jump_pixels, voxel_size=args.voxel_size,
                                                           min_points_per_voxel=args.min_points, sor_enable=args.sor,

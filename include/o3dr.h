@@ -270,6 +270,25 @@ int o3dr_cloud_big_header_dev(o3dr_ctx* ctx, void* hdr_dev);
 int o3dr_cloud_big_assume_size(o3dr_ctx* ctx, int64_t n_points);
 int o3dr_cloud_big_partition_dev(o3dr_ctx* ctx, const void* hdrs_dev, int32_t n_hdrs, int32_t n_parts, int64_t* counts_dev);
 
+/* The whole exchange in ONE call, for C++ hosts (the reference's merge sits in its C++ main flow, pose.cpp:527-532): one
+ * host thread and one context per GPU, `nccl_comm` = that GPU's ncclComm_t (RCCL over xGMI; libo3dr resolves RCCL with
+ * dlopen at first use and has no link-time dependency on it).  Steps (1)-(4) above with the small data kept in HBM (two
+ * all-gathers of a few bytes, ONE host read-back, one grouped send/receive all-to-all out of cloud_big into the second
+ * cloud buffer, the local merge over the global box), then, with gather_result != 0, an all-gather of the merged
+ * slices: `out` receives the whole merged cloud (the single-GPU result, bit for bit); with gather_result == 0 this
+ * rank's slice.  A rank that does not want the result passes out = NULL, out_capacity = 0 (it still takes part in every
+ * collective).  *n_total = points merged over all ranks.  Must be called by all ranks of the communicator.
+ * o3dr_comm_init_all / o3dr_comm_destroy wrap ncclCommInitAll / ncclCommDestroy for single-process hosts (devices ==
+ * NULL: 0 .. n_devices-1). */
+int o3dr_merge_partitioned(o3dr_ctx* ctx, void* nccl_comm, int32_t gather_result, o3dr_point* out, int64_t out_capacity,
+                           int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem);
+int o3dr_comm_init_all(int32_t n_devices, const int32_t* devices, void** comms_out);
+int o3dr_comm_destroy(void* comm);
+/* hipHostRegister / hipHostUnregister for hosts that link nothing but this ABI: page-locked frame stacks handed to
+ * o3dr_accumulate_frames with O3DR_MEM_HOST cross PCIe by DMA instead of through the runtime's bounce buffers */
+int o3dr_host_register(void* ptr, int64_t bytes);
+int o3dr_host_unregister(void* ptr);
+
 /* ---- measurement hooks (bench.py; not part of the reference surface) ------------------------ */
 /* kernel ids for o3dr_profile_* */
 #define O3DR_K_COUNT        0  /* grid-pass valid count per tile */

@@ -77,6 +77,11 @@ SYMBOLS = [
     ("o3dr_cloud_big_header_dev", C.c_int, [_vp, _vp]),
     ("o3dr_cloud_big_assume_size", C.c_int, [_vp, _i64]),
     ("o3dr_cloud_big_partition_dev", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    ("o3dr_merge_partitioned", C.c_int, [_vp, _vp, _i32, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_uint32), _i32]),
+    ("o3dr_comm_init_all", C.c_int, [_i32, _vp, _vp]),
+    ("o3dr_comm_destroy", C.c_int, [_vp]),
+    ("o3dr_host_register", C.c_int, [_vp, _i64]),
+    ("o3dr_host_unregister", C.c_int, [_vp]),
     ("o3dr_profile_enable", C.c_int, [_vp, _i32, _i32]),
     ("o3dr_profile_read", C.c_int, [_vp, _i32, C.POINTER(C.c_double), _pi64]),
     ("o3dr_profile_reset", C.c_int, [_vp]),

@@ -3,14 +3,18 @@
 // Host-side responsibilities only: argument checking, HBM workspaces, staging of host buffers,
 // batching of frames, the device-resident cloud_big, error codes.  There is no CPU compute path:
 // without a GPU o3dr_ctx_create fails and nothing else can be called.
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>  // types and enumerators only: the functions are resolved with dlsym (no link-time dependency on RCCL)
 
 #include "../../include/o3dr_testing.h"
 #include "o3dr_device.h"
@@ -108,6 +112,9 @@ struct o3dr_ctx {
     SortStats* stats_host = nullptr;   // pinned
 
     DevBuf st_disp, st_bgr, st_in, st_out, st_kp, st_kpoff, st_poses;
+    DevBuf st_xchg, st_merge, st_gather;  // o3dr_merge_partitioned: headers + count matrix, the merged slice, the gathered slices
+    uint8_t* xchg_host = nullptr;         // pinned mirror of st_xchg
+    size_t xchg_host_cap = 0;
     // host-input streaming of o3dr_accumulate_frames: two staging sets, uploads on their own stream
     DevBuf st2_disp[2], st2_bgr[2], st2_poses[2];
     hipStream_t copy_stream = nullptr;
@@ -382,6 +389,10 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     dev_release(c->st_kp);
     dev_release(c->st_kpoff);
     dev_release(c->st_poses);
+    dev_release(c->st_xchg);
+    dev_release(c->st_merge);
+    dev_release(c->st_gather);
+    if (c->xchg_host) (void)hipHostFree(c->xchg_host);
     dev_release(c->bil_tab);
     dev_release(c->st_blur);
     dev_release(c->st_blur_in);
@@ -1688,6 +1699,231 @@ extern "C" int o3dr_cloud_big_partition(o3dr_ctx* c, const float gmin[3], const 
     const uint64_t* hc = (const uint64_t*)(c->misc_host + 64);
     for (int p = 0; p < n_parts; ++p) counts[p] = (int64_t)hc[p];
     if (status) *status = ovf ? O3DR_STATUS_VOXEL_OVERFLOW : 0u;
+    return O3DR_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// The whole multi-GPU exchange behind one entry point, for C++ hosts that own RCCL communicators (one host thread and
+// one context per GPU; the reference's merge sits in its C++ main flow, pose.cpp:527-532).  RCCL is resolved with
+// dlopen/dlsym at first use: libo3dr.so itself carries no dependency on it.
+// -------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    bool ok = false;
+};
+static RcclApi* rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) return;
+        bool all = true;
+        auto sym = [&](const char* n) {
+            void* p = dlsym(api.handle, n);
+            all = all && p != nullptr;
+            return p;
+        };
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+        api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
+        api.ok = all;
+    });
+    return api.ok ? &api : nullptr;
+}
+#define NCCLCHK(R, expr)                                                                              \
+    do {                                                                                              \
+        ncclResult_t r_ = (expr);                                                                     \
+        if (r_ != ncclSuccess) {                                                                      \
+            char buf_[512];                                                                           \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(r_), __FILE__, __LINE__); \
+            g_err = buf_;                                                                             \
+            return O3DR_ERR_HIP;                                                                      \
+        }                                                                                             \
+    } while (0)
+
+extern "C" int o3dr_comm_init_all(int32_t n_devices, const int32_t* devices, void** comms_out)
+{
+    if (n_devices < 1 || n_devices > kMaxRadix || !comms_out) return fail(O3DR_ERR_INVALID_ARG, "bad arguments (1 <= n_devices <= 128)");
+    RcclApi* R = rccl_api();
+    if (!R) return fail(O3DR_ERR_HIP, "RCCL (librccl.so.1) could not be loaded");
+    std::vector<int> devs((size_t)n_devices);
+    for (int i = 0; i < n_devices; ++i) devs[(size_t)i] = devices ? devices[i] : i;
+    std::vector<ncclComm_t> comms((size_t)n_devices);
+    NCCLCHK(R, R->CommInitAll(comms.data(), n_devices, devs.data()));
+    for (int i = 0; i < n_devices; ++i) comms_out[i] = comms[(size_t)i];
+    return O3DR_OK;
+}
+extern "C" int o3dr_comm_destroy(void* comm)
+{
+    if (!comm) return O3DR_OK;
+    RcclApi* R = rccl_api();
+    if (!R) return fail(O3DR_ERR_HIP, "RCCL (librccl.so.1) could not be loaded");
+    NCCLCHK(R, R->CommDestroy((ncclComm_t)comm));
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_merge_partitioned(o3dr_ctx* c, void* nccl_comm, int32_t gather_result, o3dr_point* out, int64_t out_capacity,
+                                      int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem)
+{
+    if (n_out) *n_out = 0;
+    if (n_total) *n_total = 0;
+    if (status) *status = 0;
+    CTX_ENTER(c);
+    if (!nccl_comm || !n_out) return fail(O3DR_ERR_INVALID_ARG, "nccl_comm / n_out is NULL");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (out_capacity < 0 || (out_capacity > 0 && !out)) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
+    RcclApi* R = rccl_api();
+    if (!R) return fail(O3DR_ERR_HIP, "RCCL (librccl.so.1) could not be loaded");
+    ncclComm_t comm = (ncclComm_t)nccl_comm;
+    int W = 0, rank = 0;
+    NCCLCHK(R, R->CommCount(comm, &W));
+    NCCLCHK(R, R->CommUserRank(comm, &rank));
+    if (W < 1 || W > kMaxRadix || rank < 0 || rank >= W) return fail(O3DR_ERR_INVALID_ARG, "communicators of 1..128 ranks are supported");
+    // device scratch: own header | all headers | own counts + status | count matrix (read back in one copy from o_hdrs on)
+    const size_t o_hdr = 0, o_hdrs = 32, o_row = o_hdrs + 32 * (size_t)W, o_mat = o_row + 8 * ((size_t)W + 1);
+    const size_t total_bytes = o_mat + 8 * (size_t)W * ((size_t)W + 1);
+    CHK(dev_ensure(c, c->st_xchg, total_bytes));
+    if (c->xchg_host_cap < total_bytes) {
+        if (c->xchg_host) (void)hipHostFree(c->xchg_host);
+        c->xchg_host = nullptr;
+        c->xchg_host_cap = 0;
+        if (hipHostMalloc((void**)&c->xchg_host, total_bytes, hipHostMallocDefault) != hipSuccess) return fail(O3DR_ERR_ALLOC, "hipHostMalloc failed");
+        c->xchg_host_cap = total_bytes;
+    }
+    char* d = (char*)c->st_xchg.p;
+    // 1. headers; 2. partition against the box they span; 3. count matrix and the ONE read-back
+    CHK(o3dr_cloud_big_header_dev(c, d + o_hdr));
+    NCCLCHK(R, R->AllGather(d + o_hdr, d + o_hdrs, 32, ncclUint8, comm, c->stream));
+    CHK(o3dr_cloud_big_partition_dev(c, d + o_hdrs, W, W, (int64_t*)(d + o_row)));
+    NCCLCHK(R, R->AllGather(d + o_row, d + o_mat, (size_t)W + 1, ncclInt64, comm, c->stream));
+    HIPCHK(hipMemcpyAsync(c->xchg_host + o_hdrs, d + o_hdrs, total_bytes - o_hdrs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    struct Hdr {
+        float mn[3], mx[3];
+        int64_t count;
+    };
+    const Hdr* hdrs = (const Hdr*)(c->xchg_host + o_hdrs);
+    const int64_t* mat = (const int64_t*)(c->xchg_host + o_mat);
+    float gmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, gmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    int64_t total_pts = 0;
+    for (int r = 0; r < W; ++r) {
+        if (hdrs[r].count <= 0) continue;
+        total_pts += hdrs[r].count;
+        for (int a = 0; a < 3; ++a) {
+            gmin[a] = std::min(gmin[a], hdrs[r].mn[a]);
+            gmax[a] = std::max(gmax[a], hdrs[r].mx[a]);
+        }
+    }
+    if (n_total) *n_total = total_pts;
+    const int64_t n_local = hdrs[rank].count;
+    bool overflow = false;
+    for (int r = 0; r < W; ++r) overflow = overflow || ((mat[(size_t)r * (W + 1) + W] & 1) != 0);  // (same global box everywhere: all agree)
+    std::vector<int64_t> send((size_t)W, 0), recv((size_t)W, 0), slice_in((size_t)W, 0);
+    for (int p = 0; p < W; ++p) {
+        send[(size_t)p] = overflow ? (p == rank ? n_local : 0) : mat[(size_t)rank * (W + 1) + p];
+        recv[(size_t)p] = overflow ? (p == rank ? n_local : 0) : mat[(size_t)p * (W + 1) + rank];
+        for (int r = 0; r < W; ++r) slice_in[(size_t)p] += overflow ? (r == p ? hdrs[p].count : 0) : mat[(size_t)r * (W + 1) + p];
+    }
+    int64_t n_recv = 0, max_slice = 0;
+    for (int p = 0; p < W; ++p) n_recv += recv[(size_t)p], max_slice = std::max(max_slice, slice_in[(size_t)p]);
+    if (total_pts == 0) return O3DR_OK;
+    if (n_recv >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "a slice exceeds 2^32-1 points");
+    c->cloud_ub = n_local;  // (its own header told the host)
+    c->cloud_n_exact = true;
+    if (!overflow) {
+        // all-to-all out of cloud_big into the second cloud buffer: every peer pair has its own xGMI link; segments land in
+        // source-rank order = global frame order
+        CHK(alt_reserve(c, n_recv > 0 ? n_recv : 1));
+        NCCLCHK(R, R->GroupStart());
+        int64_t soff = 0, roff = 0;
+        for (int p = 0; p < W; ++p) {
+            if (send[(size_t)p]) NCCLCHK(R, R->Send(c->cloud_big + soff, (size_t)send[(size_t)p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream));
+            if (recv[(size_t)p]) NCCLCHK(R, R->Recv(c->cloud_alt + roff, (size_t)recv[(size_t)p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream));
+            soff += send[(size_t)p];
+            roff += recv[(size_t)p];
+        }
+        NCCLCHK(R, R->GroupEnd());
+        CHK(o3dr_cloud_big_adopt(c, n_recv));
+    }
+    // 4. local merge of the slice over the global box (the second host wait: its size)
+    CHK(dev_ensure(c, c->st_merge, (size_t)(max_slice > 0 ? max_slice : 1) * sizeof(o3dr_point)));
+    int64_t m = 0;
+    uint32_t st = 0;
+    if (n_recv > 0) CHK(finalize_impl(c, gmin, gmax, (o3dr_point*)c->st_merge.p, max_slice, &m, &st, O3DR_MEM_DEVICE));
+    if (overflow) st |= O3DR_STATUS_VOXEL_OVERFLOW;
+    if (status) *status = st;
+    const hipMemcpyKind kind = mem == O3DR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (!gather_result) {
+        if (out_capacity > 0) {
+            if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+            if (m > 0) HIPCHK(hipMemcpyAsync(out, c->st_merge.p, (size_t)m * sizeof(o3dr_point), kind, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            *n_out = m;
+        }
+        return O3DR_OK;
+    }
+    // 5. final gather: sizes, then the slices padded to the largest (rank order = ascending voxel index)
+    int64_t* mh = (int64_t*)c->xchg_host;
+    mh[0] = m;
+    HIPCHK(hipMemcpyAsync(d + o_row, mh, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(R, R->AllGather(d + o_row, d + o_mat, 1, ncclInt64, comm, c->stream));
+    HIPCHK(hipMemcpyAsync(c->xchg_host + o_mat, d + o_mat, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int64_t pad = 0, merged_total = 0;
+    for (int r = 0; r < W; ++r) pad = std::max(pad, mat[r]), merged_total += mat[r];
+    if (pad > 0) {
+        CHK(dev_ensure(c, c->st_gather, (size_t)W * (size_t)pad * sizeof(o3dr_point)));
+        NCCLCHK(R, R->AllGather(c->st_merge.p, c->st_gather.p, (size_t)pad * sizeof(o3dr_point), ncclUint8, comm, c->stream));
+    }
+    if (out_capacity > 0) {  // (a rank that does not want the result passes no buffer; it still took part in the collectives)
+        if (merged_total > out_capacity) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+        }
+        int64_t off = 0;
+        for (int r = 0; r < W; ++r) {
+            if (mat[r] > 0)
+                HIPCHK(hipMemcpyAsync(out + off, (const o3dr_point*)c->st_gather.p + (size_t)r * (size_t)pad, (size_t)mat[r] * sizeof(o3dr_point), kind, c->stream));
+            off += mat[r];
+        }
+        *n_out = merged_total;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return O3DR_OK;
+}
+
+// page-locking of caller memory (frame stacks handed to o3dr_accumulate_frames with O3DR_MEM_HOST then move by DMA)
+extern "C" int o3dr_host_register(void* ptr, int64_t bytes)
+{
+    if (!ptr || bytes <= 0) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return O3DR_OK;
+}
+extern "C" int o3dr_host_unregister(void* ptr)
+{
+    if (!ptr) return O3DR_OK;
+    HIPCHK(hipHostUnregister(ptr));
     return O3DR_OK;
 }
 

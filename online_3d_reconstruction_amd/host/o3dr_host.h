@@ -85,6 +85,9 @@ public:
     std::string outputPrefix = "output/";
     std::string read_PLY_filename0;
     int device_id = 0;
+    int n_gpus = 1;                 // --gpus N: frames sharded over devices device_id .. device_id+N-1, one host thread and
+                                    // one context each, merged through o3dr_merge_partitioned (RCCL)
+    bool partitioned_merge = false; // --partitioned_merge: take that path with one GPU as well
 
     std::vector<RawImageData> rawImageDataVec;
     std::vector<ImageData> acceptedImageDataVec;
@@ -113,6 +116,7 @@ private:
     o3dr_ctx* ctx_for_this_thread();
     void push_params(o3dr_ctx* c);
     void run_reconstruction();
+    void run_sharded(PointCloud::Ptr cloud_small);  // --gpus N
     int first_img_num = -1, last_img_num = -1;
     bool run3d_reconstruction = true;
     std::vector<std::vector<double>> pose_data, images_times_data;

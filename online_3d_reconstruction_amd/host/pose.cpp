@@ -388,6 +388,8 @@ void Pose::printUsage()
             "       [--dont_downsample] [--log 0|1] [--only_MAVLink] [--dont_icp] [--reference_fanout] [--sor 0|1]\n"
             "       [--data_dir d/] [--image_dir d/] [--disparity_dir d/] [--output_dir d/] [--calib_file f] [--device n]\n"
             "       [--keypoints_dir d/]   (d/<img_num>.txt: one \"x y\" keypoint per line; used iff jump_pixels != 1)\n"
+            "       [--gpus N]   (frames sharded over N GPUs from --device on, one host thread each; the final merge is exchanged\n"
+            "                     over RCCL and equals the one-GPU result bit for bit)  [--partitioned_merge]  (same path, N = 1)\n"
             "--sor defaults to 1: like the reference, every per-frame cloud goes through StatisticalOutlierRemoval(50, 1.0)\n"
             "before its voxel grid when jump_pixels > 0.\n"
             "./pose --downsample file.ply [--voxel_size m] [--min_points_per_voxel n]\n"
@@ -427,6 +429,8 @@ int Pose::parseCmdArgs(int argc, char** argv)
         else if (a == "--keypoints_dir") keypointsPrefix = need(i);
         else if (a == "--calib_file") calib_file = need(i);
         else if (a == "--device") device_id = atoi(need(i));
+        else if (a == "--gpus") n_gpus = atoi(need(i));
+        else if (a == "--partitioned_merge") partitioned_merge = true;
         else if (a == "--dist_nearby" || a == "--search_radius" || a == "--range_width") { need(i); }
         else if (a == "--preview" || a == "--use_segment_labels" || a == "--segment_cloud" || a == "--displayUAVPositions" ||
                  a == "--test_bad_data_rejection")
@@ -519,7 +523,12 @@ void Pose::run_reconstruction()
         const auto t3 = clk::now();
         cout << "Adding Point Cloud number/points ";
         const size_t n_acc = acceptedImageDataVec.size() - first_accepted;
-        if (reference_fanout) {
+        const bool sharded = n_gpus > 1 || partitioned_merge;
+        if (sharded) {
+            // frames are sharded over the GPUs as contiguous blocks of the WHOLE accepted list (global frame order is what
+            // the merge sums in): the clouds are made after the last cycle
+            cout << "(deferred: --gpus)";
+        } else if (reference_fanout) {
             // the reference's own structure: batches of <= 7 threads, results appended in frame order
             for (size_t i0 = first_accepted; i0 < first_accepted + n_acc; i0 += 7) {
                 const size_t nb = min<size_t>(7, first_accepted + n_acc - i0);
@@ -549,10 +558,15 @@ void Pose::run_reconstruction()
                 kp_off[k + 1] = (int64_t)(kp_xy.size() / 2);
                 cout << " " << im.raw_img_data_ptr->img_num << flush;
             }
+            // page-locked frame stacks cross PCIe by DMA (best effort: pageable memory works too)
+            (void)o3dr_host_register(disp.data(), (int64_t)disp.size());
+            (void)o3dr_host_register(bgr.data(), (int64_t)bgr.size());
             chk(o3dr_accumulate_frames_kp(c, disp.data(), (int64_t)dsz, cols, bgr.data(), (int64_t)csz, 3 * (int64_t)cols, rows,
                                           cols, poses.data(), (int32_t)n_acc, kp_xy.empty() ? nullptr : kp_xy.data(),
                                           kp_xy.empty() ? nullptr : kp_off.data(), O3DR_MEM_HOST),
                 "accumulate_frames");
+            (void)o3dr_host_unregister(disp.data());
+            (void)o3dr_host_unregister(bgr.data());
         }
         chk(o3dr_ctx_synchronize(c), "synchronize");
         const double dt = chrono::duration<double>(clk::now() - t3).count();
@@ -565,7 +579,9 @@ void Pose::run_reconstruction()
 
     // ---- final merge + save (pose.cpp:527-540) ------------------------------------------------------
     PointCloud::Ptr cloud_small(new PointCloud());
-    if (reference_fanout) {
+    if (n_gpus > 1 || partitioned_merge) {
+        run_sharded(cloud_small);
+    } else if (reference_fanout) {
         cloud_small = dont_downsample ? cloud_big_host : downsamplePtCloud(cloud_big_host, true);
     } else {
         int64_t n_big = 0, n_small = 0;
@@ -582,6 +598,84 @@ void Pose::run_reconstruction()
     cout << "Saving point clouds..." << endl;
     string path = outputPrefix + "cloud.ply";
     save_pt_cloud_to_PLY_File(cloud_small, path);
+}
+
+// --gpus N: the fan-out of pose.cpp:392-413 over GPUs instead of threads of one CPU.  Rank g (host thread g, device
+// device_id + g) takes the g-th contiguous block of the accepted frames through the batched call; o3dr_merge_partitioned
+// then exchanges the per-frame voxels by index slice over RCCL, merges every slice on its GPU and gathers the result.
+void Pose::run_sharded(PointCloud::Ptr cloud_small)
+{
+    typedef chrono::steady_clock clk;
+    const auto t0 = clk::now();
+    const size_t n_acc = acceptedImageDataVec.size();
+    if (n_gpus < 1) throw runtime_error("--gpus must be at least 1");
+    if (dont_downsample) throw runtime_error("--gpus / --partitioned_merge need the downsampling path (no --dont_downsample)");
+    if (n_acc == 0) return;
+    const RawImageData& r0 = *acceptedImageDataVec[0].raw_img_data_ptr;
+    const size_t dsz = r0.disparity_image.data.size(), csz = r0.rgb_image.data.size();
+    vector<uint8_t> disp(dsz * n_acc), bgr(csz * n_acc);
+    vector<float> poses(16 * n_acc), kp_xy;
+    vector<int64_t> kp_off(n_acc + 1, 0);
+    for (size_t k = 0; k < n_acc; ++k) {
+        const ImageData& im = acceptedImageDataVec[k];
+        memcpy(&disp[k * dsz], im.raw_img_data_ptr->disparity_image.data.data(), dsz);
+        memcpy(&bgr[k * csz], im.raw_img_data_ptr->rgb_image.data.data(), csz);
+        memcpy(&poses[16 * k], im.t_mat_FeatureMatched.data(), 64);
+        kp_xy.insert(kp_xy.end(), im.keypoints_xy.begin(), im.keypoints_xy.end());
+        kp_off[k + 1] = (int64_t)(kp_xy.size() / 2);
+    }
+    (void)o3dr_host_register(disp.data(), (int64_t)disp.size());
+    (void)o3dr_host_register(bgr.data(), (int64_t)bgr.size());
+    const int W = n_gpus;
+    vector<int32_t> devs((size_t)W);
+    for (int g = 0; g < W; ++g) devs[(size_t)g] = device_id + g;
+    vector<void*> comms((size_t)W, nullptr);
+    chk(o3dr_comm_init_all(W, devs.data(), comms.data()), "o3dr_comm_init_all");
+    // an upper bound of the merged cloud: no more cells than points, no more points than grid candidates + keypoints
+    o3dr_ctx* c0 = ctx_for_this_thread();
+    const int64_t cap = o3dr_max_points(c0, rows, cols) * (int64_t)n_acc + kp_off[n_acc] + 1;
+    cloud_small->points.resize((size_t)cap);
+    vector<string> errors((size_t)W);
+    vector<int64_t> n_out((size_t)W, 0), n_total((size_t)W, 0);
+    vector<uint32_t> st((size_t)W, 0);
+    vector<thread> th;
+    for (int g = 0; g < W; ++g) {
+        th.emplace_back([&, g]() {
+            o3dr_ctx* c = nullptr;
+            try {
+                chk(o3dr_ctx_create(devs[(size_t)g], &c), "o3dr_ctx_create");
+                push_params(c);
+                const size_t base = n_acc / (size_t)W, rem = n_acc % (size_t)W;  // contiguous blocks (dist.shard_range)
+                const size_t a = (size_t)g * base + min<size_t>((size_t)g, rem), b = a + base + ((size_t)g < rem ? 1 : 0);
+                if (b > a)
+                    chk(o3dr_accumulate_frames_kp(c, disp.data() + a * dsz, (int64_t)dsz, cols, bgr.data() + a * csz, (int64_t)csz,
+                                                  3 * (int64_t)cols, rows, cols, poses.data() + 16 * a, (int32_t)(b - a),
+                                                  kp_xy.empty() ? nullptr : kp_xy.data(), kp_xy.empty() ? nullptr : kp_off.data() + a,
+                                                  O3DR_MEM_HOST),
+                        "accumulate_frames");
+            } catch (const exception& e) {
+                errors[(size_t)g] = e.what();
+            }
+            // (every rank must enter the collective, also after a failure of its own frames: its cloud is then empty)
+            if (c) {
+                const int rc = o3dr_merge_partitioned(c, comms[(size_t)g], 1, g == 0 ? cloud_small->points.data() : nullptr, g == 0 ? cap : 0,
+                                                      &n_out[(size_t)g], &n_total[(size_t)g], &st[(size_t)g], O3DR_MEM_HOST);
+                if (rc != O3DR_OK && errors[(size_t)g].empty()) errors[(size_t)g] = string("o3dr_merge_partitioned: ") + o3dr_last_error();
+                (void)o3dr_ctx_destroy(c);
+            }
+        });
+    }
+    for (thread& t : th) t.join();
+    for (int g = 0; g < W; ++g) (void)o3dr_comm_destroy(comms[(size_t)g]);
+    (void)o3dr_host_unregister(disp.data());
+    (void)o3dr_host_unregister(bgr.data());
+    for (int g = 0; g < W; ++g)
+        if (!errors[(size_t)g].empty()) throw runtime_error("GPU " + to_string(devs[(size_t)g]) + ": " + errors[(size_t)g]);
+    cloud_small->points.resize((size_t)n_out[0]);
+    if (st[0] & O3DR_STATUS_VOXEL_OVERFLOW)
+        cerr << "[pcl::VoxelGrid::applyFilter] Leaf size is too small for the input dataset. Integer indices would overflow." << endl;
+    const double dt = chrono::duration<double>(clk::now() - t0).count();
+    cout << "\n" << W << " GPU(s): cloud_big " << n_total[0] << " points -> cloud " << n_out[0] << " points, " << dt << " sec" << endl;
 }
 
 }  // namespace o3dr_host

@@ -127,11 +127,13 @@ def test_cli_runs_config1_frames_and_matches_oracle(tmp_path, orc, Q, extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--reference_fanout", "--seq_len", "3"]])
+@pytest.mark.parametrize("extra", [[], ["--reference_fanout", "--seq_len", "3"], ["--partitioned_merge", "--seq_len", "2"]])
 def test_cli_config1_all_seven_bundled_frames(tmp_path, orc, Q, extra):
     """BASELINE config 1 on every frame of 1230-1280 the reference bundles: 1239 and 1240 are rejected
     by the variance gate (pose.cpp:187-196), 1246, 1248, 1249, 1251, 1255 accepted, all other numbers unreadable
-    (pose.cpp:164-177); the reference's literal command line (outlier removal on), cloud.ply equal to the oracle's"""
+    (pose.cpp:164-177); the reference's literal command line (outlier removal on), cloud.ply equal to the oracle's.
+    --partitioned_merge: the C++ multi-GPU path (o3dr_merge_partitioned over an RCCL communicator, here of one rank:
+    headers, index-slice partition, grouped send/receive into the second cloud buffer, merge over the global box, gather)"""
     tmp = str(tmp_path)
     names = ("1239", "1240", "1246", "1248", "1249", "1251", "1255")
     _write_dataset(tmp, names)

@@ -561,7 +561,10 @@ def test_zero_copy_exchange_single_rank_rccl(orc):
         Qs = synth.camera_Q()
         disp, bgr = synth.make_frames(7, 4)
         poses = synth.make_poses(7, 4)
-        with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=2, voxel_size=0.05), stream=torch.cuda.current_stream()) as c:
+        # the context works on the stream torch's collectives are ordered against (an explicit one: the NULL stream
+        # handle means "the context's own stream" to o3dr_ctx_set_stream)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side), o3dr.Context(0, Q=Qs, params=_params(jump_pixels=2, voxel_size=0.05), stream=side) as c:
             c.accumulateFrames(disp, bgr, poses)
             ref = c.finalize()
             view = c.cloudBigView()
