@@ -71,6 +71,7 @@ struct o3dr_ctx {
     bool bil_valid = false;
     int max_batch = 256;  // frames per launch group (O3DR_BATCH_FRAMES); also bounded by a workspace budget
     int slab_shift_env = -2;  // O3DR_SLABS=0: plain pixel order in the fused batch path; O3DR_SLABS=sN: slabs of 2^N cells; else automatic
+    int exact_box = 0;       // O3DR_EXACT_BOX=1: the batch path always takes the exact bounding box (k_reproject_bbox_count)
     int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs; 2: always runs
 
     Workspace ws;
@@ -362,6 +363,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (ru_env && atoi(ru_env) == 0) c->use_runs = 0;       // whole-cloud grids always sort points
     else if (ru_env && atoi(ru_env) == 2) c->use_runs = 2;  // ... always sort runs (default: decided per cloud on the device)
     if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
+    const char* eb_env = getenv("O3DR_EXACT_BOX");
+    c->exact_box = eb_env && atoi(eb_env) == 1;
     const char* th_env = getenv("O3DR_TEST_HOOKS");
     c->test_hooks = th_env && atoi(th_env) == 1;
     const char* sl_env = getenv("O3DR_SLABS");
@@ -1391,7 +1394,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         if (use_kp)
             launch_keypoint_pass(&c->prof, c->stream, a, kp_d, 0, c->ws.pts, c->ws.n_kp, c->ws.mm, kpoff_d + f0, nb);
         if (fused)
-            launch_reproject_fused(&c->prof, c->stream, c->ws, a, nb, cap, leaf);
+            launch_reproject_fused(&c->prof, c->stream, c->ws, a, nb, cap, leaf, !c->exact_box);
         else
             launch_reproject(&c->prof, c->stream, a, nb, c->ws.pts, c->ws.tile_cnt, c->ws.n_kp, c->ws.n_valid, c->ws.mm,
                              c->ws.scan_partial);

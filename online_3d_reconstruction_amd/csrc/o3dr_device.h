@@ -192,7 +192,7 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
 // (bounding boxes and counts first, then PCL's geometry, then the points): for launch_voxel_grid with
 // v.keys_ready = 1.  No keypoint pass (n_kp must hold zeros).
 void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, int frames, int64_t cap,
-                            const float leaf[3]);
+                            const float leaf[3], bool conservative_box = true);
 void launch_transform(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t n, const float* T16_host,
                       o3dr_point* out);
 int launch_points_minmax(Profiler* pf, hipStream_t s, const o3dr_point* in, int64_t in_fstride,

@@ -112,20 +112,31 @@ void launch_reproject(Profiler* pf, hipStream_t s, const ReprojectArgs& a, int f
 
 static inline int xcd_grid(int64_t n) { return (int)((n + kXcds - 1) / kXcds * kXcds); }  // see xcd_chunk_item
 void launch_reproject_fused(Profiler* pf, hipStream_t s, Workspace& ws, const ReprojectArgs& a, int frames, int64_t cap,
-                            const float leaf[3])
+                            const float leaf[3], bool conservative_box)
 {
     const dim3 grid(a.n_tiles, frames);
+    // rectified-stereo Q and byte disparities: counts + a conservative box from the corners of (x, y, disparity) ranges
+    // (k_reproject_count_cbox); the exact box only for frames whose conservative one trips PCL's overflow guard
+    const bool cbox = a.lut != nullptr && !a.disp_f64 && conservative_box;
+    const dim3 cgrid(cdiv64(a.n_tiles, kCountTiles), frames);
     {
         ProfScope ps(pf, O3DR_K_COUNT, s);
-        if (a.disp_f64)
-            k_reproject_bbox_count<true><<<dim3(cdiv64(a.n_tiles, kCountTiles), frames), kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
+        if (cbox)
+            k_reproject_count_cbox<kCboxTiles><<<dim3(cdiv64(a.n_tiles, kCboxTiles), frames), kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
+        else if (a.disp_f64)
+            k_reproject_bbox_count<true><<<cgrid, kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm, nullptr);
         else
-            k_reproject_bbox_count<false><<<dim3(cdiv64(a.n_tiles, kCountTiles), frames), kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm);
+            k_reproject_bbox_count<false><<<cgrid, kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm, nullptr);
     }
     {
         ProfScope ps(pf, O3DR_K_OTHER, s);
         launch_scan(s, ws.tile_cnt, a.n_tiles, a.n_tiles, frames, ws.n_valid, ws.n_kp, ws.scan_partial);
         k_voxel_geom<<<frames, 256, 0, s>>>(ws.mm, ws.mm_stride, a.n_tiles + 1, ws.n_valid, leaf[0], leaf[1], leaf[2], 0.f, ws.geom);
+    }
+    if (cbox) {
+        ProfScope ps(pf, O3DR_K_COUNT, s);
+        k_reproject_bbox_count<false><<<cgrid, kEmitThreads, 0, s>>>(a, ws.tile_cnt, ws.mm, ws.geom);
+        k_voxel_geom<<<frames, 256, 0, s>>>(ws.mm, ws.mm_stride, a.n_tiles + 1, ws.n_valid, leaf[0], leaf[1], leaf[2], 0.f, ws.geom, 1);
     }
     {
         ProfScope ps(pf, O3DR_K_REPROJECT, s);

@@ -304,6 +304,42 @@ def test_config4_overflow_frames_pass_through(ctx, orc):
     ctx.set_camera(synth.camera_Q())
 
 
+def test_conservative_box_at_the_edge_of_pcls_overflow_guard(orc, monkeypatch):
+    """The batch path lays its per-frame grids over a CONSERVATIVE bounding box (corners of the (x, y, disparity) ranges,
+    k_reproject_count_cbox) and takes the exact box only for frames whose conservative one trips PCL's overflow guard.
+    A sweep of voxel sizes that walks the per-frame grids of four frames across dx*dy*dz = INT32_MAX: every frame must
+    come out on the side the oracle's exact box puts it (pass-through or voxel grid), bit for bit; with the exact box
+    forced the library must give the same clouds."""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    Qs = synth.camera_Q()
+    disp, bgr = synth.make_frames(900, 4, invalid_frac=0.01)
+    poses = synth.make_poses(900, 4)
+    sides = set()
+    results = {}
+    for exact in ("0", "1"):
+        monkeypatch.setenv("O3DR_EXACT_BOX", exact)
+        with o3dr.Context(0, Q=Qs) as c:
+            for vs in (0.0197, 0.0198, 0.0199, 0.0200, 0.0201, 0.0202, 0.0204, 0.0232, 0.0234):
+                c.set_params(_params(jump_pixels=1, voxel_size=vs))
+                c.cloudBigReset()
+                c.accumulateFrames(disp, bgr, poses)
+                big = c.cloudBigRead()
+                _, st = c.cloudBigSize()
+                if exact == "0":
+                    ref = []
+                    for i in range(4):
+                        pts, rst = orc.create_and_transform_pt_cloud(disp[i], bgr[i], Qs, poses[i], vs, jump_pixels=1)
+                        sides.add(rst)
+                        ref.append(pts)
+                    ref = np.concatenate(ref)
+                    assert_points_equal(big, ref, f"voxel_size {vs}: cloud_big at the guard's edge")
+                    results[vs] = big
+                else:
+                    assert_points_equal(big, results[vs], f"voxel_size {vs}: exact box forced")
+    assert sides == {0, orc.STATUS_VOXEL_OVERFLOW}  # the sweep saw frames on both sides of the guard
+
+
 # ---- BASELINE's full dense size (configs[1]): 200 frames, against the oracle and through size-independent properties --
 def test_full_size_config1_200_frames(ctx, orc):
     """the headline workload itself: 200 dense 720p frames -> cloud_big (98 M points) -> merged cloud, bit for bit
@@ -611,7 +647,8 @@ def test_A7_host_streaming_many_small_batches(orc, monkeypatch):
     assert_points_equal(small, rsmall, "cloud_small (streamed host input)")
 
 
-@pytest.mark.parametrize("env", [{"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_NO_CLOUD_BOX": "1"}])
+@pytest.mark.parametrize("env", [{"O3DR_RUNS": "0"}, {"O3DR_RUNS": "2"}, {"O3DR_BATCH_FRAMES": "3"}, {"O3DR_NO_CLOUD_BOX": "1"},
+                                 {"O3DR_EXACT_BOX": "1"}])
 def test_alternate_code_paths_stay_bit_exact(orc, monkeypatch, env):
     """the switches a context reads at creation (per-point instead of per-run merge and the reverse, small launch
     groups, bounding box by a pass over the cloud) give the same bits"""
