@@ -249,6 +249,8 @@ def main():
         else:
             m1, _ = ctx.cloudBigSize()
             out = ctx.finalize(device=dev)
+        if world > 1:
+            state["exchange"] = dict(o3dist.last_stats)
         state["m1_total"] = m1
         state["m2"] = int(out.shape[0])
         state["out"] = out
@@ -370,6 +372,8 @@ def main():
         "kernel_ms_per_step": {k: round(v[0], 3) for k, v in per_kernel.items()},
         "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes)},
     }
+    if world > 1:  # collectives per step and host waits before the final gather (dist.merge_partitioned)
+        result["exchange"] = state.get("exchange")
 
     # ---- PCIe-inclusive rate: one extra, untimed-in-`value` step with HOST (pageable numpy) inputs -----------------
     if world == 1 and not args.host_inputs and not args.no_pcie_step:
