@@ -74,3 +74,21 @@ def test_null_context_is_rejected():
     rc = L.o3dr_voxel_grid(None, None, 0, leaf.ctypes.data, 0, 0.0, None, 0, C.byref(n), C.byref(st), 0)
     assert rc == -1 and n.value == 0  # invalid arg, output left empty
     assert b"ctx" in L.o3dr_last_error()
+
+
+def test_multi_gpu_entry_points_reject_bad_arguments_without_a_gpu():
+    """the exchange's entry points (include/o3dr.h, multi-GPU section) fail with a negative code and an explanation when
+    they are called without a context / communicator - before anything touches a device or loads RCCL"""
+    from online_3d_reconstruction_amd import _lib
+    L = _lib.load_library()
+    n = C.c_int64(5)
+    tot = C.c_int64(5)
+    st = C.c_uint32(5)
+    assert L.o3dr_merge_partitioned(None, None, 1, None, 0, C.byref(n), C.byref(tot), C.byref(st), 0) == -1
+    assert n.value == 0 and tot.value == 0 and st.value == 0
+    assert L.o3dr_cloud_big_header_dev(None, None) == -1
+    assert L.o3dr_cloud_big_partition_dev(None, None, 1, 1, None) == -1
+    assert L.o3dr_cloud_big_assume_size(None, 0) == -1
+    assert L.o3dr_comm_init_all(0, None, None) == -1
+    assert L.o3dr_comm_destroy(None) == 0
+    assert L.o3dr_host_register(None, 0) == -1 and L.o3dr_host_unregister(None) == 0
