@@ -44,7 +44,7 @@ def main():
     from bench import kernel_sources_sha1
     doc = {"kernel": bench_class, "kernel_symbol": "o3dr::k_" + dominant,
            "kernel_sources_sha1": kernel_sources_sha1(),  # bench.py only reports this file's traffic for the same device sources
-           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-step",
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-step --no-sor-leg",
            "hbm_bytes_per_launch": kernels.get(dominant, {}).get("hbm_bytes_per_launch"),
            "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes", "kernels": kernels}
     json.dump(doc, open(out_path, "w"), indent=1)
