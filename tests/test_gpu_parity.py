@@ -542,6 +542,22 @@ def test_A3b_sor_edge_cases(ctx, orc):
     line["x"] = np.linspace(0, 1, 4000, dtype=np.float32)
     ref, _ = orc.statistical_outlier_removal(line)
     assert_points_equal(ctx.statisticalOutlierRemoval(line), ref, "SOR line")
+    # the threshold search of the k-NN kernel (sor_prune) at exact ties: a regular lattice puts whole shells of
+    # neighbours at one distance (the 51st falls inside a shell of 8 or 12), 60-fold copies of a point make the 51
+    # smallest distances all zero (T = 0), and two far-apart clumps leave a lane's bracket spanning six decades
+    gx, gy = np.meshgrid(np.arange(90, dtype=np.float32), np.arange(70, dtype=np.float32))
+    lattice = np.zeros(gx.size, orc.POINT)
+    lattice["x"] = gx.ravel() * np.float32(0.0078125)  # 2^-7: coordinates, differences and squares are exact
+    lattice["y"] = gy.ravel() * np.float32(0.0078125)
+    lattice["rgba"] = np.arange(gx.size, dtype=np.uint32)
+    sheets = np.concatenate([lattice, lattice])  # a second sheet 2^-4 above: every column holds both
+    sheets["z"][len(lattice):] = np.float32(0.0625)
+    copies = random_cloud(100, 8, extent=(0.2, 0.2, 0.01))
+    copies = np.concatenate([np.repeat(copies[:1], 60), copies, np.repeat(copies[5:6], 51), np.repeat(copies[9:10], 200)])
+    clumps = np.concatenate([random_cloud(700, 9, extent=(0.002, 0.002, 0.002)), random_cloud(700, 10, extent=(2.0, 2.0, 0.5), origin=(40.0, 40.0, 0.0))])
+    for name, cloud in (("lattice", lattice), ("two lattice sheets", sheets), ("many copies", copies), ("clumps", clumps)):
+        ref, _ = orc.statistical_outlier_removal(cloud)
+        assert_points_equal(ctx.statisticalOutlierRemoval(cloud), ref, "SOR " + name)
 
 
 @pytest.mark.parametrize("jump", [4, 15])
