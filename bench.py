@@ -7,6 +7,11 @@ voxel grid), appended in frame order -> [N>1: index-slice partition + one RCCL a
 per-frame voxel clouds] -> combined 2.5-D merge (pose.cpp:530) [N>1: all-gather of the merged slices].  Workload = BASELINE.json configs[1]: synthetic 1280x720 dense
 (jump_pixels 1), 200 frames per GPU, voxel_size 0.05.
 
+After the timed region the default run also reports, outside `value`: the PCIe-inclusive rate (host inputs), the rate
+with the reference's statistical outlier removal on (`sor_on_frames_per_sec`, checked against the oracle), the bit-for-bit
+verification of the whole step against the oracle, the distance of the merged cloud to the reference's own std::sort
+summation order (`verification.vs_reference_sort_order*`), and the oracle timed as `cpu_baseline`.
+
     python bench.py                       # N=1, defaults finish in a few minutes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
