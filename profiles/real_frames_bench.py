@@ -24,3 +24,10 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): n, m = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print(json.dumps({"what": "200 dense 720p frames built from the five REAL accepted frames of config 1 (bundled disparities/images, lawn-mower poses)", "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(F / dt, 1), "per_frame_voxels_total": n, "merged_cells": m}))
+# the same frames with the reference's statistical outlier removal on (its literal per-frame path)
+ctx.set_params(o3dr.Params(jump_pixels=1, voxel_size=0.05, sor_enable=True))
+step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(2): n, m = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
+print(json.dumps({"what": "the same 200 real frames with statistical outlier removal on", "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(F / dt, 1), "per_frame_voxels_total": n, "merged_cells": m}))
