@@ -280,6 +280,8 @@ static int sor_ensure(o3dr_ctx* c, int frames, int64_t cap)
         size_t o_part = off; off += align256(F * 256 * 2 * 8);
         size_t o_geom = off; off += align256(F * sizeof(SorGeom));
         size_t o_n = off;    off += align256(F * 4);
+        size_t o_left = off; off += align256(F * (size_t)C * 4);
+        size_t o_lc = off;   off += align256(F * 4);
         CHK(dev_ensure(c, c->ws_sor_block, off));
         char* base = (char*)c->ws_sor_block.p;
         Workspace& w = c->ws;
@@ -290,6 +292,8 @@ static int sor_ensure(o3dr_ctx* c, int frames, int64_t cap)
         w.sor_partial = (double*)(base + o_part);
         w.sor_geom = (SorGeom*)(base + o_geom);
         w.sor_n = (uint32_t*)(base + o_n);
+        w.sor_left = (uint32_t*)(base + o_left);
+        w.sor_left_cnt = (uint32_t*)(base + o_lc);
         w.sor_max_cells = max_cells;
         w.sor_cap = C;
         c->ws_sor_cap = C;
@@ -1334,7 +1338,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
     const bool with_sor = sor_on(c) && !c->params.dont_downsample;
     int B = n_frames < c->max_batch ? n_frames : c->max_batch;
     {   // ~56 bytes of workspace per candidate point; keep a batch under 12 GiB of HBM (of 288)
-        const int64_t per_frame = (with_sor ? 56 + 42 : 56) * cap + (1 << 20);
+        const int64_t per_frame = (with_sor ? 56 + 46 : 56) * cap + (1 << 20);
         const int64_t fit = ((int64_t)12 << 30) / per_frame;
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }

@@ -130,6 +130,8 @@ struct Workspace {
     double* sor_partial = nullptr;      // frames*256*2
     o3dr_point* sor_pts = nullptr;      // frames*cap      inliers
     uint32_t* sor_n = nullptr;          // frames          inlier count
+    uint32_t* sor_left = nullptr;       // frames*cap      queries (cell-sorted index) left to k_sor_knn_left
+    uint32_t* sor_left_cnt = nullptr;   // frames
     int64_t sor_cap = 0;                // points per frame the arrays above are laid out for
     uint32_t* keep_idx = nullptr;  // frames*cap  (only when min_points > 1)
     uint32_t* run_start = nullptr; // frames*(cap+1)  first point of every group run (grouped path), + sentinel

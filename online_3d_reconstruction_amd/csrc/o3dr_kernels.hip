@@ -431,8 +431,15 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
             ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part, tm);
     }
     k_sor_gather<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(in, in_fstride, ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom, cap, ws.sor_xyz);
+    (void)hipMemsetAsync(ws.sor_left_cnt, 0, (size_t)F * 4, s);
     k_sor_knn<<<dim3(cdiv64(cap, kWave), F), kWave, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_first, cell_stride,
-                                                           ws.sor_geom, cap, ws.sor_dist);
+                                                           ws.sor_geom, cap, ws.sor_dist, ws.sor_left, ws.sor_left_cnt);
+    {   // the queries the wave-shared search handed over (a looping grid: their number is only known on the device)
+        int lg = cdiv64(cap, kWave * kSorLeftWaves);
+        if (lg > 1024) lg = 1024;
+        k_sor_knn_left<<<dim3(lg, F), kSorLeftWaves * kWave, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_first, cell_stride,
+                                                                    ws.sor_geom, cap, ws.sor_dist, ws.sor_left, ws.sor_left_cnt);
+    }
     k_sor_partial<<<dim3(kSorStatBlocks, F), 256, 0, s>>>(ws.sor_dist, cap, ws.sor_geom, ws.sor_partial);
     k_sor_threshold<<<cdiv64(F, 64), 64, 0, s>>>(ws.sor_partial, stddev_mul, ws.sor_geom, F);
     k_sor_count<<<dim3(n_tiles, F), 256, 0, s>>>(ws.sor_dist, cap, ws.sor_geom, n_tiles, ws.tile_cnt);
