@@ -63,6 +63,12 @@ def main():
         raw = open(f"{REF}/data_files/{name}", "rb").read()
         with gzip.GzipFile(f"{OUT}/{name}.gz", "wb", mtime=0) as g:
             g.write(raw)
+    # positions an earlier run of the reference wrote, one "tx,ty,tz" line per accepted image (the translation of the
+    # pose row its timestamp search bound to that image): lines 1-25 are images 1242..1266, lines 26-30 are images
+    # 1295, 1297, 1298, 1299, 1301; later lines belong to other runs appended to the same file and are not kept
+    lines = open(f"{REF}/output/hexPosMAVLink.txt").read().splitlines()[:30]
+    with open(f"{OUT}/hexPosMAVLink_first30.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
     print("Q =", Q.ravel())
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(f"{OUT}/{f}"))

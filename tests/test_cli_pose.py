@@ -51,6 +51,19 @@ def test_pose_binding_of_frame_1248_matches_survey():
     assert np.allclose(row[3:10], [7.70684, -12.120081, 21.99, 0.003113, -0.000385, 0.409214, -0.912433], atol=1e-6)
 
 
+def test_pose_binding_equals_the_positions_a_reference_run_wrote():
+    """build/output/hexPosMAVLink.txt of the reference holds what generateUAVpos (pose_functions.cpp:1815) returned for
+    each image an earlier run accepted: the translation of the pose row bound to it, printed as float with 6 significant
+    digits.  Its first 30 lines (tests/golden/hexPosMAVLink_first30.txt, data only) are images 1242..1266 and 1295,
+    1297, 1298, 1299, 1301: the timestamp search restated here binds every one of them to a row with that translation."""
+    lines = open(os.path.join(GOLDEN, "hexPosMAVLink_first30.txt")).read().split()
+    images = list(range(1242, 1267)) + [1295, 1297, 1298, 1299, 1301]
+    assert len(lines) == len(images) == 30
+    for img, line in zip(images, lines):
+        _, row = pose_row_for_image(img)
+        assert ",".join("%.6g" % float(np.float32(v)) for v in row[3:6]) == line, img
+
+
 def _write_dataset(tmp, names=("1248", "1249")):
     from PIL import Image
     for d in ("data_files", "images", "disparities", "output"):
