@@ -542,9 +542,10 @@ def test_A3b_sor_edge_cases(ctx, orc):
     line["x"] = np.linspace(0, 1, 4000, dtype=np.float32)
     ref, _ = orc.statistical_outlier_removal(line)
     assert_points_equal(ctx.statisticalOutlierRemoval(line), ref, "SOR line")
-    # the threshold search of the k-NN kernel (sor_prune) at exact ties: a regular lattice puts whole shells of
-    # neighbours at one distance (the 51st falls inside a shell of 8 or 12), 60-fold copies of a point make the 51
-    # smallest distances all zero (T = 0), and two far-apart clumps leave a lane's bracket spanning six decades
+    # the selection of the k-NN kernel (sor_merge; a threshold search in the round's first version) at exact ties: a
+    # regular lattice puts whole shells of neighbours at one distance (the 51st falls inside a shell of 8 or 12), 60-fold
+    # copies of a point make the 51 smallest distances all zero (bound 0), and two far-apart clumps spread a lane's
+    # distances over six decades
     gx, gy = np.meshgrid(np.arange(90, dtype=np.float32), np.arange(70, dtype=np.float32))
     lattice = np.zeros(gx.size, orc.POINT)
     lattice["x"] = gx.ravel() * np.float32(0.0078125)  # 2^-7: coordinates, differences and squares are exact
