@@ -277,6 +277,7 @@ static int sor_ensure(o3dr_ctx* c, int frames, int64_t cap)
         size_t o_pts = off;  off += align256(F * (size_t)C * 16);
         size_t o_dist = off; off += align256(F * (size_t)C * 4);
         size_t o_cf = off;   off += align256(F * ((size_t)max_cells + 1) * 4);
+        size_t o_cz = off;   off += align256(F * ((size_t)max_cells + 1) * 8);
         size_t o_part = off; off += align256(F * 256 * 2 * 8);
         size_t o_geom = off; off += align256(F * sizeof(SorGeom));
         size_t o_n = off;    off += align256(F * 4);
@@ -289,6 +290,7 @@ static int sor_ensure(o3dr_ctx* c, int frames, int64_t cap)
         w.sor_pts = (o3dr_point*)(base + o_pts);
         w.sor_dist = (float*)(base + o_dist);
         w.sor_cell_first = (uint32_t*)(base + o_cf);
+        w.sor_cell_z = (float2*)(base + o_cz);
         w.sor_partial = (double*)(base + o_part);
         w.sor_geom = (SorGeom*)(base + o_geom);
         w.sor_n = (uint32_t*)(base + o_n);
@@ -1338,7 +1340,7 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
     const bool with_sor = sor_on(c) && !c->params.dont_downsample;
     int B = n_frames < c->max_batch ? n_frames : c->max_batch;
     {   // ~56 bytes of workspace per candidate point; keep a batch under 12 GiB of HBM (of 288)
-        const int64_t per_frame = (with_sor ? 56 + 46 : 56) * cap + (1 << 20);
+        const int64_t per_frame = (with_sor ? 56 + 50 : 56) * cap + (1 << 20);
         const int64_t fit = ((int64_t)12 << 30) / per_frame;
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }

@@ -126,6 +126,7 @@ struct Workspace {
     float4* sor_xyz = nullptr;          // frames*cap      coordinates in cell order
     float* sor_dist = nullptr;          // frames*cap      mean neighbour distance per point
     uint32_t* sor_cell_first = nullptr; // frames*(sor_max_cells+1): points in cells below c (exclusive scan of the populations)
+    float2* sor_cell_z = nullptr;       // frames*(sor_max_cells+1): z range of every cell's points (for the handed-over queries)
     uint32_t sor_max_cells = 0;
     double* sor_partial = nullptr;      // frames*256*2
     o3dr_point* sor_pts = nullptr;      // frames*cap      inliers

@@ -437,8 +437,11 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     {   // the queries the wave-shared search handed over (a looping grid: their number is only known on the device)
         int lg = cdiv64(cap, kWave * kSorLeftWaves);
         if (lg > 1024) lg = 1024;
+        int zg = cdiv64((int64_t)ws.sor_max_cells, 256);
+        if (zg > 256) zg = 256;
+        k_sor_cell_z<<<dim3(zg, F), 256, 0, s>>>(ws.sor_xyz, ws.sor_cell_first, cell_stride, ws.sor_geom, cap, ws.sor_left_cnt, ws.sor_cell_z);
         k_sor_knn_left<<<dim3(lg, F), kSorLeftWaves * kWave, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_first, cell_stride,
-                                                                    ws.sor_geom, cap, ws.sor_dist, ws.sor_left, ws.sor_left_cnt);
+                                                                    ws.sor_geom, cap, ws.sor_dist, ws.sor_left, ws.sor_left_cnt, ws.sor_cell_z);
     }
     k_sor_partial<<<dim3(kSorStatBlocks, F), 256, 0, s>>>(ws.sor_dist, cap, ws.sor_geom, ws.sor_partial);
     k_sor_threshold<<<cdiv64(F, 64), 64, 0, s>>>(ws.sor_partial, stddev_mul, ws.sor_geom, F);
