@@ -418,8 +418,7 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     const int64_t cell_stride = (int64_t)ws.sor_max_cells + 1;
     k_sor_plan<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, mm_used, n_dev, ws.sor_max_cells, ws.sor_geom, ws.geom);
     (void)hipMemsetAsync(ws.sor_cell_first, 0, (size_t)F * (size_t)cell_stride * 4, s);
-    k_sor_cells<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(in, in_fstride, ws.sor_geom, cap, ws.keys[0], cell_stride, ws.sor_cell_first);
-    launch_scan(s, ws.sor_cell_first, cell_stride, cell_stride, F, nullptr, nullptr, ws.scan_partial);
+    k_sor_cells<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(in, in_fstride, ws.sor_geom, cap, ws.keys[0]);
     for (int pass = 0; pass < kMaxPasses; ++pass) {
         k_radix_hist<<<dim3(n_sort_tiles, F), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist,
                                                                     ws.hist_part, tm);
@@ -430,6 +429,8 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
         k_radix_scatter_lane<<<dim3(xcd_grid((int64_t)n_sort_tiles * kScatParts), F), kScatThreads, 0, s>>>(
             ws.keys[0], ws.vals[0], ws.keys[1], ws.vals[1], cap, ws.geom, pass, n_sort_tiles, ws.hist, ws.hist_part, tm);
     }
+    k_sor_cell_counts<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(ws.keys[0], ws.keys[1], ws.geom, ws.sor_geom, cap, cell_stride, ws.sor_cell_first);
+    launch_scan(s, ws.sor_cell_first, cell_stride, cell_stride, F, nullptr, nullptr, ws.scan_partial);
     k_sor_gather<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(in, in_fstride, ws.vals[0], ws.vals[1], ws.sor_geom, ws.geom, cap, ws.sor_xyz);
     (void)hipMemsetAsync(ws.sor_left_cnt, 0, (size_t)F * 4, s);
     k_sor_knn<<<dim3(cdiv64(cap, kWave), F), kWave, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_first, cell_stride,

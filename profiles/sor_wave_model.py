@@ -6,7 +6,7 @@ to see where the kernel's vector instructions go: 7.2 per candidate (ISA), ~1 58
 on synthetic frame 0 with 30 points per column it counts ~1 250 candidates and 7.0 merges per wave = 21.5 k instructions,
 against 21-23 k measured (SQ_INSTS_VALU).  Statistics only: the points come from a plain float64 reprojection here.
 
-    python profiles/sor_wave_model.py [points per column = 30] [waves sampled = 150]
+    python profiles/sor_wave_model.py [points per column = 30] [waves sampled = 150] [--real=1248]
 """
 import os
 import sys
@@ -16,14 +16,21 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from online_3d_reconstruction_amd import synth  # noqa: E402
 
-CELLPTS = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
-N_WAVES = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+REAL = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--real=")), None)
+ARGS = [a for a in sys.argv[1:] if not a.startswith("--")]
+CELLPTS = float(ARGS[0]) if len(ARGS) > 0 else 30.0
+N_WAVES = int(ARGS[1]) if len(ARGS) > 1 else 150
 PRUNE_AT, CHECK_EVERY, K, RING_CAP, MIN_LIVE = 48, 16, 51, 2, 12
 
 
 def frame_points(index, rows=720, cols=1280, bb=20, min_disp=64):
     Q = synth.camera_Q(rows, cols)
     disp, _ = synth.make_frame(index, rows, cols)
+    if REAL:  # one of the bundled real frames (tests/golden, data only) under the synthetic pose, like real_frames_bench.py
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        Q = np.load(os.path.join(root, "tests", "golden", "cam13calib_Q.npy"))
+        disp = np.load(os.path.join(root, "tests", "golden", f"frame_{REAL}.npz"))["disp"]
+        rows, cols = disp.shape
     T = np.asarray(synth.make_pose(index), np.float64).reshape(4, 4)
     cs = cols // 8
     v, u = np.mgrid[bb:rows - bb, cs:cols - bb]
