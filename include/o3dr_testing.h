@@ -15,6 +15,12 @@ extern "C" {
  * That call must return O3DR_ERR_INTERNAL with *n_out = 0 (never a GPU fault), and the context stays usable. */
 int o3dr_test_corrupt_next_gather(o3dr_ctx* ctx);
 
+/* The mean neighbour distances (pcl::StatisticalOutlierRemoval's `distances`, one per input point, input order) the
+ * last o3dr_statistical_outlier_removal of this context computed for its n_in points: the inlier set alone says little
+ * about an outlier's own distance, so the parity tests compare these with the oracle's bit for bit.  out: n floats in
+ * host memory; n must not exceed that call's n_in. */
+int o3dr_test_sor_distances(o3dr_ctx* ctx, float* out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ SYMBOLS = [
     ("o3dr_profile_reset", C.c_int, [_vp]),
     ("o3dr_profile_stats", C.c_int, [_vp, _pi64]),
     ("o3dr_test_corrupt_next_gather", C.c_int, [_vp]),
+    ("o3dr_test_sor_distances", C.c_int, [_vp, _vp, _i64]),
     ("o3dr_device_info", C.c_int, [_vp, C.c_char_p, _i32, C.POINTER(_i32), _pi64]),
 ]
 

@@ -2005,6 +2005,17 @@ extern "C" int o3dr_test_corrupt_next_gather(o3dr_ctx* c)
     return O3DR_OK;
 }
 
+extern "C" int o3dr_test_sor_distances(o3dr_ctx* c, float* out, int64_t n)
+{
+    CTX_ENTER(c);
+    if (!c->test_hooks) return fail(O3DR_ERR_INVALID_ARG, "test hooks are off (create the context with O3DR_TEST_HOOKS=1)");
+    if (!out || n < 0 || n > c->ws_sor_cap || !c->ws.sor_dist) return fail(O3DR_ERR_INVALID_ARG, "no outlier removal of that size has run");
+    if (n == 0) return O3DR_OK;
+    HIPCHK(hipMemcpyAsync(out, c->ws.sor_dist, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return O3DR_OK;
+}
+
 extern "C" int o3dr_profile_enable(o3dr_ctx* c, int32_t kernel_id, int32_t enable)
 {
     CTX_ENTER(c);

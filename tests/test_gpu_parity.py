@@ -561,6 +561,54 @@ def test_A3b_sor_edge_cases(ctx, orc):
         assert_points_equal(ctx.statisticalOutlierRemoval(cloud), ref, "SOR " + name)
 
 
+def test_A3b_sor_mean_distances_bit_exact(orc, Q, frame_1248, monkeypatch):
+    """The inlier set says little about an outlier's own distance (it stays an outlier with a slightly wrong one): the
+    per-point mean neighbour distances themselves - every query of the shared-stream kernel and of the one-wave-per-query
+    kernel with its per-cell lower bounds - against the oracle's, bit for bit (include/o3dr_testing.h)."""
+    import ctypes as C
+
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import _lib as L
+    from online_3d_reconstruction_amd import synth
+    monkeypatch.setenv("O3DR_TEST_HOOKS", "1")
+    rng = np.random.default_rng(77)
+    clouds = {"random": random_cloud(60000, 501, extent=(3.0, 2.0, 0.3))}
+    slab = random_cloud(30000, 502, extent=(1.5, 1.0, 0.02))
+    spikes = slab.copy()  # depth spikes far off a dense surface, and points pushed out to the corners of the bounding box
+    idx = rng.choice(len(slab), 300, replace=False)
+    spikes["z"][idx] += rng.uniform(0.05, 1.5, 300).astype(np.float32) * rng.choice([-1, 1], 300).astype(np.float32)
+    spikes["x"][idx[:20]] += np.float32(3.0)
+    spikes["y"][idx[20:40]] -= np.float32(2.5)
+    spikes["x"][idx[40:50]] -= np.float32(4.0)
+    spikes["y"][idx[40:50]] += np.float32(4.0)
+    clouds["spikes"] = spikes
+    dup = random_cloud(3000, 4, extent=(0.5, 0.5, 0.01))
+    dup[1000:2000] = dup[:1000]
+    clouds["duplicates"] = dup
+    gx, gy = np.meshgrid(np.arange(90, dtype=np.float32), np.arange(70, dtype=np.float32))
+    lattice = np.zeros(gx.size, orc.POINT)
+    lattice["x"] = gx.ravel() * np.float32(0.0078125)
+    lattice["y"] = gy.ravel() * np.float32(0.0078125)
+    clouds["lattice"] = lattice
+    line = np.zeros(4000, orc.POINT)
+    line["x"] = np.linspace(0, 1, 4000, dtype=np.float32)
+    clouds["line"] = line
+    disp, bgr = frame_1248
+    _, row = __import__("test_cli_pose").pose_row_for_image(1248)
+    clouds["frame 1248"] = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1),
+                                                  synth.generate_tmat(row[3:6], row[6:10]))
+    lib = o3dr.load_library()
+    with o3dr.Context(0, Q=Q) as c:
+        for name, cloud in clouds.items():
+            ref_kept, ref_dist = orc.statistical_outlier_removal(cloud)
+            got_kept = c.statisticalOutlierRemoval(cloud)
+            assert_points_equal(got_kept, ref_kept, f"SOR {name}")
+            dist = np.empty(len(cloud), np.float32)
+            L.check(lib.o3dr_test_sor_distances(c._h, dist.ctypes.data_as(C.c_void_p), len(cloud)))
+            bad = np.nonzero(dist.view(np.uint32) != ref_dist.view(np.uint32))[0]
+            assert len(bad) == 0, f"{name}: {len(bad)} of {len(cloud)} mean distances differ, first at {bad[:5]}: {dist[bad[:5]]} vs {ref_dist[bad[:5]]}"
+
+
 @pytest.mark.parametrize("jump", [4, 15])
 def test_A6_with_sor_matches_reference_pipeline(ctx, orc, Q, frame_1248, jump):
     """the reference's full per-frame path: A1 -> A2 -> SOR -> VoxelGrid"""
