@@ -283,6 +283,13 @@ int64_t orc_voxel_grid(const orc_point* in, int64_t n, const float leaf[3], uint
                 sb += (float)(p->rgba & 255u);
                 sa += (float)((p->rgba >> 24) & 255u);
             }
+            /* PCL 1.8 AccumulatorXYZ::get: `xyz / n` on an Eigen::Vector3f - a TRUE division per coefficient by float(n)
+             * from Eigen 3.2 on (scalar_quotient1_op: `a / m_other`; Eigen 3.0 / 3.1 multiplied by the reciprocal for
+             * non-integer scalars).  The reference's build used the system Eigen at /usr/include/eigen3
+             * (build/CMakeCache.txt:350, 1188); its version string was not recorded (:933 `[v()]`), but the same cache
+             * pins PCL 1.8 (:412, released 2016), Boost 1.61 and CUDA 8.0 - an Ubuntu 14.04 / 16.04 system, whose
+             * packaged Eigen is 3.2.0 / 3.2.92: division either way.  AccumulatorRGBA::get divides its float sums by n
+             * the same way and truncates to uint32. */
             const float nf = (float)(uint64_t)(i - index);
             orc_point o;
             o.x = sx / nf;
@@ -620,10 +627,23 @@ static int reflect101(int p, int len) /* cv::borderInterpolate(p, len, BORDER_RE
     return p;
 }
 
-void orc_bilateral_filter_u8(const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
-                             double sigma_color, double sigma_space, int32_t order, uint8_t* dst, int64_t dst_pitch)
+/* What bilateralFilter_8u sets up before its row loop, for cn interleaved channels: the reflect-101 padded copy, the
+ * colour weights (index = sum over the channels of |v - v0|, so 256 * cn entries), the space weights and offsets of the
+ * neighbours inside the disc.  Shared by the one-channel call of the hot path (pose_functions.cpp:1044) and the
+ * three-channel form, whose output the reference holds (build/output/bilateralFiltered_15.png, _31.png: 1248.png through
+ * exactly this call with d = 15 / 31, sigmaColor = 2 d, sigmaSpace = d / 2 in integer arithmetic;
+ * tests/test_oracle_golden.py::test_bilateral_filter_equals_the_reference_runs_own_output). */
+typedef struct {
+    int radius, maxk, tw, th, cn;
+    uint8_t* temp;
+    float* color_weight;
+    float* space_weight;
+    int* space_ofs;
+} bilateral_setup;
+
+static void bilateral_prepare(bilateral_setup* b, const uint8_t* src, int64_t src_pitch, int rows, int cols, int cn, int d,
+                              double sigma_color, double sigma_space)
 {
-    if (rows <= 0 || cols <= 0) return;
     if (sigma_color <= 0) sigma_color = 1;
     if (sigma_space <= 0) sigma_space = 1;
     const double gauss_color_coeff = -0.5 / (sigma_color * sigma_color);
@@ -631,28 +651,52 @@ void orc_bilateral_filter_u8(const uint8_t* src, int64_t src_pitch, int32_t rows
     int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) /* cvRound */ : d / 2;
     if (radius < 1) radius = 1;
     d = radius * 2 + 1;
-
+    b->radius = radius;
+    b->cn = cn;
     /* copyMakeBorder(src, temp, radius, radius, radius, radius, BORDER_DEFAULT) */
     const int tw = cols + 2 * radius, th = rows + 2 * radius;
-    uint8_t* temp = (uint8_t*)malloc((size_t)tw * (size_t)th);
+    b->tw = tw;
+    b->th = th;
+    b->temp = (uint8_t*)malloc((size_t)tw * (size_t)th * cn);
     for (int y = 0; y < th; ++y) {
         const uint8_t* srow = src + (int64_t)reflect101(y - radius, rows) * src_pitch;
-        for (int x = 0; x < tw; ++x) temp[(size_t)y * tw + x] = srow[reflect101(x - radius, cols)];
+        for (int x = 0; x < tw; ++x)
+            for (int c = 0; c < cn; ++c) b->temp[((size_t)y * tw + x) * cn + c] = srow[reflect101(x - radius, cols) * cn + c];
     }
-    float color_weight[256];
-    float* space_weight = (float*)malloc(sizeof(float) * (size_t)d * d);
-    int* space_ofs = (int*)malloc(sizeof(int) * (size_t)d * d);
-    for (int i = 0; i < 256; ++i) color_weight[i] = (float)exp(i * i * gauss_color_coeff);
+    b->color_weight = (float*)malloc(sizeof(float) * 256 * cn);
+    b->space_weight = (float*)malloc(sizeof(float) * (size_t)d * d);
+    b->space_ofs = (int*)malloc(sizeof(int) * (size_t)d * d);
+    for (int i = 0; i < 256 * cn; ++i) b->color_weight[i] = (float)exp(i * i * gauss_color_coeff);
     int maxk = 0;
     for (int i = -radius; i <= radius; ++i)
         for (int j = -radius; j <= radius; ++j) {
             const double r = sqrt((double)i * i + (double)j * j);
             if (r > radius) continue;
-            space_weight[maxk] = (float)exp(r * r * gauss_space_coeff);
-            space_ofs[maxk++] = i * tw + j;
+            b->space_weight[maxk] = (float)exp(r * r * gauss_space_coeff);
+            b->space_ofs[maxk++] = (i * tw + j) * cn;
         }
+    b->maxk = maxk;
+}
+
+static void bilateral_release(bilateral_setup* b)
+{
+    free(b->space_ofs);
+    free(b->space_weight);
+    free(b->color_weight);
+    free(b->temp);
+}
+
+void orc_bilateral_filter_u8(const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
+                             double sigma_color, double sigma_space, int32_t order, uint8_t* dst, int64_t dst_pitch)
+{
+    if (rows <= 0 || cols <= 0) return;
+    bilateral_setup b;
+    bilateral_prepare(&b, src, src_pitch, rows, cols, 1, d, sigma_color, sigma_space);
+    const int radius = b.radius, tw = b.tw, maxk = b.maxk;
+    const float *color_weight = b.color_weight, *space_weight = b.space_weight;
+    const int* space_ofs = b.space_ofs;
     for (int i = 0; i < rows; ++i) {
-        const uint8_t* sptr = temp + (size_t)(i + radius) * tw + radius;
+        const uint8_t* sptr = b.temp + (size_t)(i + radius) * tw + radius;
         uint8_t* dptr = dst + (int64_t)i * dst_pitch;
         for (int j = 0; j < cols; ++j) {
             float sum = 0, wsum = 0;
@@ -682,9 +726,63 @@ void orc_bilateral_filter_u8(const uint8_t* src, int64_t src_pitch, int32_t rows
             dptr[j] = (uint8_t)lrintf(sum / wsum); /* cvRound: round half to even */
         }
     }
-    free(space_ofs);
-    free(space_weight);
-    free(temp);
+    bilateral_release(&b);
+}
+
+/* The same call on CV_8UC3 (the cn == 3 branch of BilateralFilter_8u_Invoker): one weight per neighbour from the summed
+ * channel differences, three weighted sums, `wsum = 1.f / wsum; b0 = cvRound(sum_b * wsum)`.  Not on the hot path (the
+ * reference only filters disparities); it exists because the reference HOLDS outputs of this branch, and it shares its
+ * border, tables, neighbour order and four-at-a-time grouping with the one-channel branch above. */
+void orc_bilateral_filter_u8c3(const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
+                               double sigma_color, double sigma_space, int32_t order, uint8_t* dst, int64_t dst_pitch)
+{
+    if (rows <= 0 || cols <= 0) return;
+    bilateral_setup b;
+    bilateral_prepare(&b, src, src_pitch, rows, cols, 3, d, sigma_color, sigma_space);
+    const int radius = b.radius, tw = b.tw, maxk = b.maxk;
+    const float *color_weight = b.color_weight, *space_weight = b.space_weight;
+    const int* space_ofs = b.space_ofs;
+    for (int i = 0; i < rows; ++i) {
+        const uint8_t* sptr = b.temp + ((size_t)(i + radius) * tw + radius) * 3;
+        uint8_t* dptr = dst + (int64_t)i * dst_pitch;
+        for (int j = 0; j < cols * 3; j += 3) {
+            float sum_b = 0, sum_g = 0, sum_r = 0, wsum = 0;
+            const int b0 = sptr[j], g0 = sptr[j + 1], r0 = sptr[j + 2];
+            int k = 0;
+            if (order == ORC_BILATERAL_SSE3) {
+                for (; k <= maxk - 4; k += 4) {
+                    float w[4], bw[4], gw[4], rw[4];
+                    for (int q = 0; q < 4; ++q) {
+                        const uint8_t* sk = sptr + j + space_ofs[k + q];
+                        const int bb = sk[0], gg = sk[1], rr = sk[2];
+                        w[q] = color_weight[abs(bb - b0) + abs(gg - g0) + abs(rr - r0)] * space_weight[k + q];
+                        bw[q] = (float)bb * w[q];
+                        gw[q] = (float)gg * w[q];
+                        rw[q] = (float)rr * w[q];
+                    }
+                    /* hadd(_w,_b), hadd(_g,_r), hadd of the two: every sum as (a0+a1)+(a2+a3) */
+                    wsum += (w[0] + w[1]) + (w[2] + w[3]);
+                    sum_b += (bw[0] + bw[1]) + (bw[2] + bw[3]);
+                    sum_g += (gw[0] + gw[1]) + (gw[2] + gw[3]);
+                    sum_r += (rw[0] + rw[1]) + (rw[2] + rw[3]);
+                }
+            }
+            for (; k < maxk; ++k) {
+                const uint8_t* sk = sptr + j + space_ofs[k];
+                const int bb = sk[0], gg = sk[1], rr = sk[2];
+                const float w = space_weight[k] * color_weight[abs(bb - b0) + abs(gg - g0) + abs(rr - r0)];
+                sum_b += bb * w;
+                sum_g += gg * w;
+                sum_r += rr * w;
+                wsum += w;
+            }
+            wsum = 1.f / wsum;
+            dptr[j] = (uint8_t)lrintf(sum_b * wsum);
+            dptr[j + 1] = (uint8_t)lrintf(sum_g * wsum);
+            dptr[j + 2] = (uint8_t)lrintf(sum_r * wsum);
+        }
+    }
+    bilateral_release(&b);
 }
 
 /* Pose::getMean / Pose::getVariance, pose_functions.cpp:987-1028 (planeFitted == false) */

@@ -105,11 +105,17 @@ int64_t orc_run_frames_order(const uint8_t* disp, int64_t disp_fstride, int64_t 
  * non-IPP build (the IPP branch is compiled out in 3.1.0).  order: how the per-pixel float sums are grouped —
  * ORC_BILATERAL_SSE3: groups of four neighbours reduced pairwise with haddps, then added (x86-64 builds, which
  * the reference's CMakeCache.txt shows); ORC_BILATERAL_SCALAR: one neighbour after the other (builds without SSE3).
- * The weight tables use the host's exp(); parity unpinned like the rest of this oracle. */
+ * The weight tables use the host's exp().  PINNED by an output of the reference itself (round 4): the three-channel
+ * branch of the same invoker, orc_bilateral_filter_u8c3 — same border, tables, neighbour order, four-at-a-time grouping,
+ * cvRound — reproduces build/output/bilateralFiltered_15.png and _31.png (build/images/1248.png through the call of
+ * pose_functions.cpp:1044 with blur_kernel 15 / 31) byte for byte in the SSE3 order; the scalar order does not. */
 #define ORC_BILATERAL_SSE3   0
 #define ORC_BILATERAL_SCALAR 1
 void orc_bilateral_filter_u8(const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
                              double sigma_color, double sigma_space, int32_t order, uint8_t* dst, int64_t dst_pitch);
+/* CV_8UC3 (interleaved B,G,R) through the cn == 3 branch; test infrastructure for the pin above, not on the hot path */
+void orc_bilateral_filter_u8c3(const uint8_t* src, int64_t src_pitch, int32_t rows, int32_t cols, int32_t d,
+                               double sigma_color, double sigma_space, int32_t order, uint8_t* dst, int64_t dst_pitch);
 
 /* frame gate — Pose::getVariance(disp, false), pose_functions.cpp:987-1028 (mean over the ROI of the
  * disparities > min_disparity, divided by the full ROI size; sequential fp64 sums in row-major order). */

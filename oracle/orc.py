@@ -60,6 +60,8 @@ def lib():
         L.orc_voxel_keys.argtypes = [vp, i64, vp, vp, vp, vp]
         L.orc_bilateral_filter_u8.restype = None
         L.orc_bilateral_filter_u8.argtypes = [vp, i64, i32, i32, i32, dbl, dbl, i32, vp, i64]
+        L.orc_bilateral_filter_u8c3.restype = None
+        L.orc_bilateral_filter_u8c3.argtypes = [vp, i64, i32, i32, i32, dbl, dbl, i32, vp, i64]
         L.orc_disparity_variance.restype = dbl
         L.orc_disparity_variance.argtypes = [vp, i64, i32, i32, i32, i32, dbl]
         _lib = L
@@ -207,6 +209,18 @@ def bilateral_filter(disp, d, sigma_color, sigma_space, order=BILATERAL_SSE3):
     out = np.empty_like(disp)
     lib().orc_bilateral_filter_u8(_p(disp), disp.strides[0], rows, cols, int(d), float(sigma_color), float(sigma_space),
                                   int(order), _p(out), out.strides[0])
+    return out
+
+
+def bilateral_filter_bgr(bgr, d, sigma_color, sigma_space, order=BILATERAL_SSE3):
+    """cv::bilateralFilter on a CV_8UC3 image: the cn == 3 branch of the same OpenCV 3.1 invoker (the reference holds
+    outputs of it: build/output/bilateralFiltered_15.png / _31.png)"""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    rows, cols, cn = bgr.shape
+    assert cn == 3
+    out = np.empty_like(bgr)
+    lib().orc_bilateral_filter_u8c3(_p(bgr), bgr.strides[0], rows, cols, int(d), float(sigma_color), float(sigma_space),
+                                    int(order), _p(out), out.strides[0])
     return out
 
 

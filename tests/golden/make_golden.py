@@ -69,6 +69,17 @@ def main():
     lines = open(f"{REF}/output/hexPosMAVLink.txt").read().splitlines()[:30]
     with open(f"{OUT}/hexPosMAVLink_first30.txt", "w") as f:
         f.write("\n".join(lines) + "\n")
+    # outputs of cv::bilateralFilter the reference holds: build/images/1248.png through the call of pose_functions.cpp:1044
+    # with blur_kernel 15 / 31 (decoded pixels, B,G,R like cv::imread); the input is frame_1248.npz's `bgr`
+    for d in (15, 31):
+        t = np.array(Image.open(f"{REF}/output/bilateralFiltered_{d}.png").convert("RGB"))
+        np.savez_compressed(f"{OUT}/bilateralFiltered_{d}.npz", bgr=np.ascontiguousarray(t[:, :, ::-1]))
+    # build/cloud_uavpos.ply (pose.cpp:551-553): 42 feature-matched positions followed by the 42 MAVLink positions of the
+    # same accepted images, as "x y z r g b" text lines (%.9g round-trips a float32)
+    _, v, _ = read_ply_vertices(f"{REF}/cloud_uavpos.ply")
+    with open(f"{OUT}/cloud_uavpos_vertices.txt", "w") as f:
+        for p in v:
+            f.write("%.9g %.9g %.9g %d %d %d\n" % (p["x"], p["y"], p["z"], p["r"], p["g"], p["b"]))
     print("Q =", Q.ravel())
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(f"{OUT}/{f}"))

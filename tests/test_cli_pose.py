@@ -64,6 +64,37 @@ def test_pose_binding_equals_the_positions_a_reference_run_wrote():
         assert ",".join("%.6g" % float(np.float32(v)) for v in row[3:6]) == line, img
 
 
+def test_pose_binding_equals_the_uav_positions_in_the_reference_runs_cloud_uavpos_ply():
+    """build/cloud_uavpos.ply is an output of the reference (pose.cpp:551-553): the 42 feature-matched positions of a
+    run's accepted images followed by their 42 MAVLink positions - for each accepted image the translation of the pose
+    row its timestamp search bound to it (generateUAVpos, pose_functions.cpp:1815), as float32.  Which images that run
+    accepted is not recorded, but the binding restated here must be able to produce every one of them: each of the 42
+    positions is, bit for bit in float32, the translation this binding gives some image of images.txt, and images can
+    be chosen in strictly increasing order (accepted images are visited in order; two neighbouring images often bind
+    to the same pose row, which is why positions repeat).  tests/golden/cloud_uavpos_vertices.txt holds the vertices."""
+    v = np.loadtxt(os.path.join(GOLDEN, "cloud_uavpos_vertices.txt"))
+    assert v.shape == (84, 6)
+    fm, mav = v[:42], v[42:]
+    assert (fm[:, 3:] == [0, 255, 0]).all() and (mav[:, 3:] == [255, 0, 0]).all()  # pose_functions.cpp:1815-1837 colours
+    pose, imgs = _tables()
+    bound = {}
+    for num, _, t in imgs:
+        try:
+            bound[int(num)] = pose[_search_using_time(pose[:, 2], t), 3:6].astype(np.float32)
+        except RuntimeError:
+            pass
+    last = 0
+    chosen = []
+    for p in mav[:, :3].astype(np.float32):
+        cands = [n for n, b in bound.items() if n > last and np.array_equal(b, p)]
+        assert cands, f"no image after {last} binds to {p}"
+        last = min(cands)
+        chosen.append(last)
+    # the run behind the file covered the bundled range: frame 1248's pose row (SURVEY 8c(3)) is among them
+    assert 1247 in chosen or 1248 in chosen
+    assert chosen[0] >= 1199 and chosen[-1] <= 1300
+
+
 def _write_dataset(tmp, names=("1248", "1249")):
     from PIL import Image
     for d in ("data_files", "images", "disparities", "output"):

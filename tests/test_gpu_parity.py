@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_points_equal, random_cloud
+from conftest import GOLDEN, assert_points_equal, random_cloud
 
 pytestmark = pytest.mark.gpu
 
@@ -151,6 +151,30 @@ def test_A3a_A5_downsample_pt_cloud(ctx, orc, Q, frame_1248, vs, minpts):
     # one output point per occupied XY cell (the invariant build/cloud.ply shows)
     cells = np.stack([np.floor(comb["x"] / np.float32(vs)), np.floor(comb["y"] / np.float32(vs))], 1)
     assert len(np.unique(cells, axis=0)) == len(comb)
+
+
+def test_A5_merged_z_sits_on_the_grid_of_the_reference_runs_own_cloud(ctx):
+    """Every z of the reference's own build/cloud.ply is an exact multiple of 2^-15 m - what the fp32 `z += 500` ...
+    `z -= 500` round trip of pose_functions.cpp:1664-1666,1702-1704 leaves (tests/test_oracle_golden.py::
+    test_bundled_cloud_ply_z_carries_the_fp32_plus_500_round_trip).  The GPU's combined merge leaves the same fingerprint
+    on its own output; the same grid without the round trip (o3dr_voxel_grid with the combined leaf) does not; and the
+    merge of the bundled cloud.ply itself (one point per cell: every centroid is the point) returns its z unchanged."""
+    def on_grid(z):
+        q = z.astype(np.float64) * 2.0 ** 15
+        return q == np.rint(q)
+    pts = random_cloud(300000, 12, extent=(6.0, 5.0, 3.0), origin=(2.0, -7.0, -3.0))
+    ctx.set_params(_params(voxel_size=0.05))
+    merged = ctx.downsamplePtCloud(pts, True)
+    assert len(merged) > 1000 and on_grid(merged["z"]).all()
+    plain = ctx.voxelGrid(pts, np.array([0.05, 0.05, 1000.0], np.float32), 1)
+    assert len(plain) == len(merged) and on_grid(plain["z"]).mean() < 0.01
+    v = np.load(os.path.join(GOLDEN, "cloud_ply.npz"))["vertices"]
+    p = np.zeros(len(v), merged.dtype)
+    p["x"], p["y"], p["z"] = v["x"], v["y"], v["z"]
+    p["rgba"] = (v["r"].astype(np.uint32) << 16) | (v["g"].astype(np.uint32) << 8) | v["b"]
+    again = ctx.downsamplePtCloud(p, True)
+    assert len(again) == len(v) == 55940 and on_grid(again["z"]).all()
+    assert np.array_equal(np.sort(again["z"]), np.sort(v["z"]))
 
 
 def test_A3a_within_tolerance_of_reference_sort_order(ctx, orc):

@@ -133,6 +133,67 @@ def test_bundled_cloud_ply_is_one_point_per_xy_cell(orc):
     assert st == 0 and len(out) == 55940
 
 
+def _on_grid(z, exp=-15):
+    """every value an exact multiple of 2**exp"""
+    q = z.astype(np.float64) * 2.0 ** -exp
+    return q == np.rint(q)
+
+
+def test_bundled_cloud_ply_z_carries_the_fp32_plus_500_round_trip(orc):
+    """Every z of the reference's own build/cloud.ply is an exact multiple of 2^-15 m: the fingerprint of
+    pose_functions.cpp:1664-1666 (`z += 500` in fp32 puts z into [256, 512), where one ulp is 2^-15), the fp32 centroid
+    of values on that grid divided back onto it, and `z -= 500` (:1702-1704), which is exact.  x and y (never shifted)
+    are not on any such grid.  The oracle's combined merge leaves the same fingerprint on a random cloud, and the same
+    grid WITHOUT the +-500 (o3dr's A4 with the combined leaf) does not: the +500 is a real fp32 operation in the
+    restatement, not an algebraic no-op."""
+    v = np.load(os.path.join(GOLDEN, "cloud_ply.npz"))["vertices"]
+    assert _on_grid(v["z"]).all()
+    assert not _on_grid(v["x"]).all() and not _on_grid(v["y"]).all()
+    assert np.abs(v["z"]).max() < 256 - 500 + 500  # (the argument above needs z + 500 inside [256, 512))
+    pts = random_cloud(200000, 11, extent=(6.0, 5.0, 3.0), origin=(2.0, -7.0, -3.0))
+    merged, st = orc.downsample_pt_cloud(pts, 0.05, True, 1)
+    assert st == 0 and len(merged) > 1000
+    assert _on_grid(merged["z"]).all()
+    plain, st = orc.voxel_grid(pts, np.array([0.05, 0.05, 1000.0], np.float32), 1)
+    assert st == 0 and len(plain) == len(merged)  # same cells ...
+    assert _on_grid(plain["z"]).mean() < 0.01      # ... but z straight from the fp32 mean: off the grid
+    assert np.abs(plain["z"] - merged["z"]).max() < 1e-3
+
+
+def test_bilateral_filter_equals_the_reference_runs_own_output(orc, frame_1248):
+    """build/output/bilateralFiltered_15.png and _31.png are outputs of the reference's own cv::bilateralFilter
+    (OpenCV 3.1.0): build/images/1248.png through the call of pose_functions.cpp:1044 with blur_kernel 15 / 31, i.e.
+    (d, sigmaColor, sigmaSpace) = (bk, bk * 2, bk / 2 in INTEGER arithmetic: 7 and 15, not 7.5 and 15.5).  The oracle's
+    three-channel branch reproduces all 2 764 800 bytes of both in the SSE3 summation order - and not in the scalar
+    order, nor with sigmaSpace = bk / 2.0 - which pins the reflect-101 border, the exp() weight tables, the neighbour
+    order, the (a0+a1)+(a2+a3) grouping and the rounding that the one-channel branch of the hot path
+    (orc_bilateral_filter_u8, what the GPU's k_bilateral_u8 is compared with) shares with it."""
+    _, bgr = frame_1248
+    for bk in (15, 31):
+        want = np.load(os.path.join(GOLDEN, f"bilateralFiltered_{bk}.npz"))["bgr"]
+        got = orc.bilateral_filter_bgr(bgr, bk, bk * 2, bk // 2, orc.BILATERAL_SSE3)
+        assert np.array_equal(got, want), f"blur_kernel {bk}: {(got != want).sum()} bytes differ"
+        scalar = orc.bilateral_filter_bgr(bgr, bk, bk * 2, bk // 2, orc.BILATERAL_SCALAR)
+        assert 0 < (scalar != want).sum() < 1000
+    frac = orc.bilateral_filter_bgr(bgr, 15, 30, 7.5, orc.BILATERAL_SSE3)
+    assert (frac != np.load(os.path.join(GOLDEN, "bilateralFiltered_15.npz"))["bgr"]).sum() > 10000
+
+
+def test_one_channel_bilateral_is_the_pinned_three_channel_branch_on_grey_input(orc, frame_1248):
+    """Ties the hot path's CV_8UC1 branch to the pinned CV_8UC3 one: on an image whose three channels are equal the
+    three-channel branch looks its colour weight up at 3 |v - v0|, i.e. it is the one-channel branch with sigmaColor
+    three times smaller; per channel the two then run the same sums - up to the last step, `sum / wsum` against
+    `sum * (1.f / wsum)`, which may differ by one level where the quotient sits next to a rounding boundary."""
+    disp, _ = frame_1248
+    img = np.ascontiguousarray(disp[200:420, 300:640])
+    grey3 = np.repeat(img[:, :, None], 3, axis=2)
+    one = orc.bilateral_filter(img, 15, 30.0 / 3.0, 7)
+    three = orc.bilateral_filter_bgr(grey3, 15, 30.0, 7)
+    assert np.array_equal(three[:, :, 0], three[:, :, 1]) and np.array_equal(three[:, :, 0], three[:, :, 2])
+    d = np.abs(one.astype(int) - three[:, :, 0].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
 def test_voxel_grid_against_bruteforce(orc):
     """Occupancy, order, counts and centroids against an independent numpy grouping."""
     pts = random_cloud(20000, 7, extent=(2.0, 1.5, 0.5))
