@@ -63,6 +63,20 @@ def _grid_shape(rows, cols, jump, bb=20, cutout=8):
     return max(0, -(-(rows - 2 * bb) // jump)), max(0, -(-(cols - bb - cs) // jump))
 
 
+def baseline_config(args, total_frames):
+    """which entry of BASELINE.json `configs` (0-based, as in the file) this run's shape is"""
+    shape = (args.rows, args.cols, args.jump_pixels, args.voxel_size, args.min_points)
+    if shape == (720, 1280, 1, 0.05, 1):
+        return "BASELINE.json configs[2]: 2000 frames in all" if total_frames == 2000 else "BASELINE.json configs[1]"
+    if shape == (1080, 1920, 1, 0.02, 3):
+        return "BASELINE.json configs[3]"
+    if shape == (2160, 4096, 4, 0.05, 1):
+        return "BASELINE.json configs[4]" + (": 2000 frames in all" if total_frames == 2000 else " shape")
+    if shape == (720, 1280, 15, 0.05, 1):
+        return "BASELINE.json configs[0] shape, synthetic frames"
+    return "not a BASELINE.json config"
+
+
 def kernel_sources_sha1():
     """hash of the device sources: ties a PMC traffic file to the kernels it was measured on"""
     import glob
@@ -157,8 +171,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through torch's launcher
+            # (before anything here touches the GPU; never an exec) and relay rank 0's JSON line, which the children
+            # print on the stdout they inherit
+            import socket
+            import subprocess
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd))
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -365,7 +390,7 @@ def main():
         "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: gloo, one GPU)" if rehearsal else ""),
         "config": {"workload": f"synthetic {args.cols}x{args.rows} dense stereo, jump_pixels {args.jump_pixels}, "
                                f"{F} frames/GPU, voxel_size {args.voxel_size}, min_points_per_voxel {args.min_points}, "
-                               f"SOR {'on' if args.sor else 'off'}, " + (f"blur_kernel {args.blur_kernel}, " if args.blur_kernel > 1 else "") + f"frames resident in HBM (BASELINE.json configs[1])",
+                               f"SOR {'on' if args.sor else 'off'}, " + (f"blur_kernel {args.blur_kernel}, " if args.blur_kernel > 1 else "") + f"frames resident in HBM ({baseline_config(args, F * world)})",
                    "frames_per_gpu": F, "rows": args.rows, "cols": args.cols, "jump_pixels": args.jump_pixels,
                    "voxel_size": args.voxel_size, "parallelism": f"frame-sharded x{world}"},
         "mpoints_per_sec_into_global_cloud": round(m1_total * args.steps / dt / 1e6, 2),
@@ -377,8 +402,25 @@ def main():
         "kernel_ms_per_step": {k: round(v[0], 3) for k, v in per_kernel.items()},
         "sort": {"records_per_step": int(sort_recs), "record_passes_per_step": int(rec_passes)},
     }
-    if world > 1:  # collectives per step and host waits before the final gather (dist.merge_partitioned)
+    if world > 1:  # collectives per step, host waits before the final gather, and what the exchange moved (dist.merge_partitioned)
         result["exchange"] = state.get("exchange")
+        ex = state.get("exchange") or {}
+        mine3 = torch.tensor([ex.get("points_local", 0), ex.get("points_sent_off_rank", 0), ex.get("points_received_off_rank", 0)],
+                             dtype=torch.int64, device=comm_dev or dev)
+        all3 = torch.empty(3 * world, dtype=torch.int64, device=comm_dev or dev)
+        dist.all_gather_into_tensor(all3, mine3)
+        all3 = all3.cpu().numpy().reshape(world, 3)
+        sent_total = int(all3[:, 1].sum())
+        # xGMI model (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, one link per peer pair): the all-to-all is bound by
+        # the busiest rank's bytes over the links it uses; the figure is a MODEL, nothing here measures a link
+        busiest = int(max(all3[:, 1].max(), all3[:, 2].max())) * 16
+        result["exchange_volume"] = {
+            "points_local_per_rank": [int(v) for v in all3[:, 0]], "points_sent_off_rank_per_rank": [int(v) for v in all3[:, 1]],
+            "points_received_off_rank_per_rank": [int(v) for v in all3[:, 2]],
+            "fraction_of_points_leaving_their_rank": round(sent_total / max(int(all3[:, 0].sum()), 1), 4),
+            "bytes_over_links_total": sent_total * 16, "busiest_rank_bytes": busiest,
+            "modelled_xgmi_ms_one_link": round(busiest / 153e9 * 1e3, 3),
+            "modelled_xgmi_ms_links_to_all_peers": round(busiest / (153e9 * max(min(world - 1, 7), 1)) * 1e3, 3)}
 
     # ---- PCIe-inclusive rate: one extra, untimed-in-`value` step with HOST (pageable numpy) inputs -----------------
     if world == 1 and not args.host_inputs and not args.no_pcie_step:

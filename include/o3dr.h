@@ -56,6 +56,7 @@ extern "C" {
 #define O3DR_ERR_NOT_CONFIGURED -5 /* o3dr_set_camera not called yet */
 #define O3DR_ERR_ALLOC          -6
 #define O3DR_ERR_INTERNAL       -7 /* a device-side consistency guard tripped (O3DR_STATUS_INTERNAL): results are invalid */
+#define O3DR_ERR_PEER           -8 /* o3dr_merge_partitioned: another rank failed; every rank left the exchange together */
 
 /* `mem` values */
 #define O3DR_MEM_HOST   0
@@ -282,6 +283,20 @@ int o3dr_cloud_big_partition_dev(o3dr_ctx* ctx, const void* hdrs_dev, int32_t n_
  * NULL: 0 .. n_devices-1). */
 int o3dr_merge_partitioned(o3dr_ctx* ctx, void* nccl_comm, int32_t gather_result, o3dr_point* out, int64_t out_capacity,
                            int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem);
+/* Failure is COLLECTIVE: a rank whose own step fails (its header, the partition, an allocation, the local merge) keeps
+ * taking part in the collectives that remain with an error word in place of its data - the header's count, a word next
+ * to the slice counts, the merged size - and every rank returns at the same point: the failing rank with its own code,
+ * the others with O3DR_ERR_PEER.  No rank is left waiting inside a collective its peer never enters.  (Buffers that
+ * have to grow between the count matrix and the all-to-all are agreed on with one more 8-byte all-gather, only in calls
+ * in which some rank - known to all from the capacities sent with the counts - has to grow one.)  After an error every
+ * context stays usable and cloud_big keeps its points (possibly reordered by slice: a later merge gives the same
+ * result).  What cannot be made collective is a failure of RCCL itself (O3DR_ERR_HIP).
+ * o3dr_merge_partitioned_stats: what the last call of this context moved - out[0] points of this rank before the
+ * exchange, [1] points sent to other ranks, [2] points received from other ranks, [3] / [4] the same in bytes (what
+ * crosses xGMI), [5] points entering this rank's merge, [6] agreement rounds (0 or 1), [7] points of all ranks.
+ * o3dr_cloud_big_capacity: points the cloud buffer and the receive buffer hold without reallocating. */
+int o3dr_merge_partitioned_stats(o3dr_ctx* ctx, int64_t out[8]);
+int o3dr_cloud_big_capacity(o3dr_ctx* ctx, int64_t* cloud_points, int64_t* recv_points);
 int o3dr_comm_init_all(int32_t n_devices, const int32_t* devices, void** comms_out);
 int o3dr_comm_destroy(void* comm);
 /* hipHostRegister / hipHostUnregister for hosts that link nothing but this ABI: page-locked frame stacks handed to

@@ -21,6 +21,19 @@ int o3dr_test_corrupt_next_gather(o3dr_ctx* ctx);
  * host memory; n must not exceed that call's n_in. */
 int o3dr_test_sor_distances(o3dr_ctx* ctx, float* out, int64_t n);
 
+/* o3dr_merge_partitioned with W > 1 ranks on ONE GPU.  RCCL refuses two ranks on one device, so the multi-rank paths of
+ * the exchange (slice sizes, segment order, failure agreement, statistics) would otherwise only ever run with one rank:
+ * a LOCAL communicator connects n_ranks contexts of one process - one host thread each, all on the same device - through
+ * device-to-device copies and a host barrier (a rank that does not show up within 30 s breaks it: O3DR_ERR_PEER).  The
+ * protocol code is the one o3dr_merge_partitioned runs over RCCL; only the two transport primitives differ.
+ * o3dr_test_fail_at: step `point` of this context's next exchange fails on this rank as an allocation would
+ * (1 header, 2 partition, 3 buffers before the all-to-all, 4 local merge). */
+int o3dr_test_local_comm_create(int32_t n_ranks, void** comm_out);
+int o3dr_test_local_comm_destroy(void* comm);
+int o3dr_test_merge_partitioned_local(o3dr_ctx* ctx, void* local_comm, int32_t rank, int32_t gather_result, o3dr_point* out,
+                                      int64_t out_capacity, int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem);
+int o3dr_test_fail_at(o3dr_ctx* ctx, int32_t point);
+
 #ifdef __cplusplus
 }
 #endif

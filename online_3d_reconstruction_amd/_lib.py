@@ -10,7 +10,7 @@ _LIB = os.path.join(_HERE, "lib", "libo3dr.so")
 POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
 
 OK = 0
-ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_NOT_CONFIGURED, ERR_ALLOC, ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_NOT_CONFIGURED, ERR_ALLOC, ERR_INTERNAL, ERR_PEER = -1, -2, -3, -4, -5, -6, -7, -8
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_VOXEL_OVERFLOW = 1
 STATUS_INTERNAL = 0x80000000
@@ -78,6 +78,8 @@ SYMBOLS = [
     ("o3dr_cloud_big_assume_size", C.c_int, [_vp, _i64]),
     ("o3dr_cloud_big_partition_dev", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("o3dr_merge_partitioned", C.c_int, [_vp, _vp, _i32, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_uint32), _i32]),
+    ("o3dr_merge_partitioned_stats", C.c_int, [_vp, _pi64]),
+    ("o3dr_cloud_big_capacity", C.c_int, [_vp, _pi64, _pi64]),
     ("o3dr_comm_init_all", C.c_int, [_i32, _vp, _vp]),
     ("o3dr_comm_destroy", C.c_int, [_vp]),
     ("o3dr_host_register", C.c_int, [_vp, _i64]),
@@ -88,6 +90,10 @@ SYMBOLS = [
     ("o3dr_profile_stats", C.c_int, [_vp, _pi64]),
     ("o3dr_test_corrupt_next_gather", C.c_int, [_vp]),
     ("o3dr_test_sor_distances", C.c_int, [_vp, _vp, _i64]),
+    ("o3dr_test_local_comm_create", C.c_int, [_i32, C.POINTER(_vp)]),
+    ("o3dr_test_local_comm_destroy", C.c_int, [_vp]),
+    ("o3dr_test_merge_partitioned_local", C.c_int, [_vp, _vp, _i32, _i32, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_uint32), _i32]),
+    ("o3dr_test_fail_at", C.c_int, [_vp, _i32]),
     ("o3dr_device_info", C.c_int, [_vp, C.c_char_p, _i32, C.POINTER(_i32), _pi64]),
 ]
 

@@ -366,8 +366,17 @@ class Context:
         """this rank's 32-byte exchange header {min xyz, max xyz (f32), count (i64)} as a uint8 CUDA tensor; asynchronous"""
         import torch
         hdr = torch.empty(32, dtype=torch.uint8, device=torch.device("cuda", self.device))
+        self._order_after_torch()
         L.check(self._lib.o3dr_cloud_big_header_dev(self._h, hdr.data_ptr()))
         return hdr
+
+    def _order_after_torch(self):
+        """The library writes on the context's stream into a block torch's allocator handed out on torch's current
+        stream: when the two differ, the block's previous use on torch's stream must finish first."""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        if self.stream_raw != cur.cuda_stream:
+            cur.synchronize()
 
     def cloudBigPartitionDev(self, hdrs, n_parts):
         """hdrs: the all-gathered headers ([world*32] uint8, CUDA).  Stable reorder of cloud_big by index slice of the
@@ -376,9 +385,24 @@ class Context:
         import torch
         assert hdrs.is_cuda and hdrs.is_contiguous() and hdrs.numel() % 32 == 0
         counts = torch.empty(n_parts + 1, dtype=torch.int64, device=hdrs.device)
+        self._order_after_torch()
         L.check(self._lib.o3dr_cloud_big_partition_dev(self._h, hdrs.data_ptr(), hdrs.numel() // 32, int(n_parts), counts.data_ptr()))
         self._keep = hdrs  # (the launches read it)
         return counts
+
+    def cloudBigCapacity(self):
+        """(points cloud_big holds, points the receive buffer holds) without reallocating"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        L.check(self._lib.o3dr_cloud_big_capacity(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def mergePartitionedStats(self):
+        """what this context's last o3dr_merge_partitioned moved (include/o3dr.h)"""
+        out = (C.c_int64 * 8)()
+        L.check(self._lib.o3dr_merge_partitioned_stats(self._h, out))
+        keys = ("points_local", "points_sent_off_rank", "points_received_off_rank", "bytes_sent", "bytes_received",
+                "points_into_merge", "agreement_rounds", "points_all_ranks")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def cloudBigAssumeSize(self, n_points):
         """the caller read this rank's header back: cloud_big holds exactly n_points (saves the library its own round trips)"""

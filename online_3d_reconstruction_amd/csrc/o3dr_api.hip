@@ -9,7 +9,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -121,6 +123,8 @@ struct o3dr_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: consumed by the next voxel grid
+    int test_fail_at = 0;  // o3dr_test_fail_at: the numbered step of the next o3dr_merge_partitioned fails on this rank
+    int64_t xchg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // o3dr_merge_partitioned_stats
     int test_hooks = 0;    // O3DR_TEST_HOOKS=1 at o3dr_ctx_create: the entry points of include/o3dr_testing.h act
     int host_batch = 32;  // frames per upload while the previous batch computes (O3DR_HOST_BATCH_FRAMES)
     Profiler prof;
@@ -1344,14 +1348,15 @@ static int accumulate_impl(o3dr_ctx* c, const uint8_t* disp, int64_t disp_frame_
         const int64_t fit = ((int64_t)12 << 30) / per_frame;
         if (fit < B) B = fit < 1 ? 1 : (int)fit;
     }
+    // Host buffers: frames cross PCIe once.  Upload batch k+1 on a second stream while batch k
+    // computes (two staging sets); smaller batches than the HBM-resident path so that they overlap
+    // (clamped BEFORE the workspaces are sized: a streaming call never launches more than host_batch frames)
+    const bool streaming = mem == O3DR_MEM_HOST;
+    if (streaming && c->host_batch < B) B = c->host_batch;
     CHK(ws_ensure(c, B, cap, true));
     if (with_sor) CHK(sor_ensure(c, B, cap));
 
-    const bool streaming = mem == O3DR_MEM_HOST;
     if (streaming) {
-        // Host buffers: frames cross PCIe once.  Upload batch k+1 on a second stream while batch k
-        // computes (two staging sets); smaller batches than the HBM-resident path so that they overlap.
-        if (c->host_batch < B) B = c->host_batch;
         if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             if (!c->ev_copied[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
@@ -1792,26 +1797,151 @@ extern "C" int o3dr_comm_destroy(void* comm)
     return O3DR_OK;
 }
 
-extern "C" int o3dr_merge_partitioned(o3dr_ctx* c, void* nccl_comm, int32_t gather_result, o3dr_point* out, int64_t out_capacity,
-                                      int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem)
+// ---- transports of the exchange -----------------------------------------------------------------------------------------
+// The protocol below only needs "all-gather a few bytes" and "move my slice segments to their owners"; RCCL provides
+// both for real ranks.  The LOCAL transport (include/o3dr_testing.h) connects W contexts of ONE process - one host thread
+// each, all on the same device - through device-to-device copies and a host barrier, so that the very code that runs over
+// RCCL (sizes, slices, failure agreement, statistics) is exercised with W > 1 on a one-GPU box, where RCCL refuses two
+// ranks on one device.
+struct Transport {
+    int W = 1, rank = 0;
+    virtual ~Transport() {}
+    // every rank contributes `bytes` at send_dev; recv_dev receives W * bytes in rank order (ordered on c->stream)
+    virtual int all_gather(o3dr_ctx* c, const void* send_dev, void* recv_dev, size_t bytes) = 0;
+    // send[p] points starting at send_base + sum(send[0..p)) go to rank p; recv[p] points from rank p land at
+    // recv_base + sum(recv[0..p)): segments arrive in source-rank order
+    virtual int all_to_all(o3dr_ctx* c, const o3dr_point* send_base, const int64_t* send, o3dr_point* recv_base, const int64_t* recv) = 0;
+};
+
+struct RcclTransport : Transport {
+    RcclApi* R = nullptr;
+    ncclComm_t comm = nullptr;
+    int all_gather(o3dr_ctx* c, const void* send_dev, void* recv_dev, size_t bytes) override
+    {
+        NCCLCHK(R, R->AllGather(send_dev, recv_dev, bytes, ncclUint8, comm, c->stream));
+        return O3DR_OK;
+    }
+    int all_to_all(o3dr_ctx* c, const o3dr_point* send_base, const int64_t* send, o3dr_point* recv_base, const int64_t* recv) override
+    {
+        // every peer pair has its own xGMI link.  An error inside the group must not leave it open: ncclGroupEnd is
+        // always reached, the first error is reported after it.
+        NCCLCHK(R, R->GroupStart());
+        ncclResult_t first = ncclSuccess;
+        int64_t soff = 0, roff = 0;
+        for (int p = 0; p < W; ++p) {
+            if (send[p] && first == ncclSuccess) first = R->Send(send_base + soff, (size_t)send[p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream);
+            if (recv[p] && first == ncclSuccess) first = R->Recv(recv_base + roff, (size_t)recv[p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream);
+            soff += send[p];
+            roff += recv[p];
+        }
+        const ncclResult_t endr = R->GroupEnd();
+        NCCLCHK(R, first);
+        NCCLCHK(R, endr);
+        return O3DR_OK;
+    }
+};
+
+struct LocalComm {  // test transport: shared by the W rank threads
+    int W = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    std::vector<const void*> ptr;
+    std::vector<const int64_t*> cnt;
+    // false: a rank did not show up within 30 s (it left the protocol: exactly what the tests look for)
+    bool barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
+        const uint64_t g = generation;
+        if (++waiting == W) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return generation != g || broken; })) {
+            broken = true;
+            cv.notify_all();
+            return false;
+        }
+        return !broken;
+    }
+};
+struct LocalTransport : Transport {
+    LocalComm* L = nullptr;
+    int all_gather(o3dr_ctx* c, const void* send_dev, void* recv_dev, size_t bytes) override
+    {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        L->ptr[(size_t)rank] = send_dev;
+        if (!L->barrier()) return fail(O3DR_ERR_PEER, "local transport: a rank left the exchange (all-gather)");
+        for (int r = 0; r < W; ++r)
+            HIPCHK(hipMemcpyAsync((char*)recv_dev + (size_t)r * bytes, L->ptr[(size_t)r], bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!L->barrier()) return fail(O3DR_ERR_PEER, "local transport: a rank left the exchange (all-gather)");
+        return O3DR_OK;
+    }
+    int all_to_all(o3dr_ctx* c, const o3dr_point* send_base, const int64_t* send, o3dr_point* recv_base, const int64_t* recv) override
+    {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        L->ptr[(size_t)rank] = send_base;
+        L->cnt[(size_t)rank] = send;
+        if (!L->barrier()) return fail(O3DR_ERR_PEER, "local transport: a rank left the exchange (all-to-all)");
+        int64_t roff = 0;
+        int rc = O3DR_OK;
+        for (int p = 0; p < W && rc == O3DR_OK; ++p) {
+            int64_t soff = 0;
+            for (int q = 0; q < rank; ++q) soff += L->cnt[(size_t)p][q];
+            if (L->cnt[(size_t)p][rank] != recv[p]) rc = fail(O3DR_ERR_INTERNAL, "local transport: send and receive counts differ");
+            else if (recv[p] && hipMemcpyAsync(recv_base + roff, (const o3dr_point*)L->ptr[(size_t)p] + soff, (size_t)recv[p] * sizeof(o3dr_point),
+                                               hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                rc = fail(O3DR_ERR_HIP, "local transport: copy failed");
+            roff += recv[p];
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == O3DR_OK) rc = fail(O3DR_ERR_HIP, "local transport: sync failed");
+        if (!L->barrier()) return fail(O3DR_ERR_PEER, "local transport: a rank left the exchange (all-to-all)");
+        return rc;
+    }
+};
+
+// What one rank tells the others with the slice counts (all-gather #2): W counts, then
+//   [W]     status word of the partition (bit 0: PCL's overflow guard on the global box)
+//   [W + 1] this rank's error so far (0, or a negative O3DR_ERR_* code: every rank then leaves the exchange together)
+//   [W + 2] points its receive buffer (the alternate cloud) holds now
+//   [W + 3] points its merged-slice buffer holds now
+//   [W + 4] points its gather buffer holds now
+// With the capacities every rank knows whether ANY rank has to grow a buffer before the all-to-all.  If none has to
+// (every call after the first of a run), nothing can fail locally between the count matrix and the merge, and the
+// exchange goes on without another word; else the ranks that must allocate do so and one more 8-byte all-gather
+// carries the outcome, so that a failed allocation stops every rank before the all-to-all instead of leaving the
+// others inside it.
+static constexpr int kRowExtra = 5;
+
+static int peer_error(int own, int first_rank, int64_t first_code, const std::string& own_msg)
 {
-    if (n_out) *n_out = 0;
-    if (n_total) *n_total = 0;
-    if (status) *status = 0;
-    CTX_ENTER(c);
-    if (!nccl_comm || !n_out) return fail(O3DR_ERR_INVALID_ARG, "nccl_comm / n_out is NULL");
-    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
-    if (out_capacity < 0 || (out_capacity > 0 && !out)) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
-    RcclApi* R = rccl_api();
-    if (!R) return fail(O3DR_ERR_HIP, "RCCL (librccl.so.1) could not be loaded");
-    ncclComm_t comm = (ncclComm_t)nccl_comm;
-    int W = 0, rank = 0;
-    NCCLCHK(R, R->CommCount(comm, &W));
-    NCCLCHK(R, R->CommUserRank(comm, &rank));
+    char buf[256];
+    if (own != O3DR_OK) {
+        snprintf(buf, sizeof buf, "%s [every rank left the exchange]", own_msg.c_str());
+        g_err = buf;
+        return own;
+    }
+    snprintf(buf, sizeof buf, "rank %d failed with code %lld: every rank left the exchange together", first_rank, (long long)first_code);
+    g_err = buf;
+    return O3DR_ERR_PEER;
+}
+
+static int merge_partitioned_impl(o3dr_ctx* c, Transport& T, int32_t gather_result, o3dr_point* out, int64_t out_capacity,
+                                  int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem)
+{
+    const int W = T.W, rank = T.rank;
     if (W < 1 || W > kMaxRadix || rank < 0 || rank >= W) return fail(O3DR_ERR_INVALID_ARG, "communicators of 1..128 ranks are supported");
-    // device scratch: own header | all headers | own counts + status | count matrix (read back in one copy from o_hdrs on)
-    const size_t o_hdr = 0, o_hdrs = 32, o_row = o_hdrs + 32 * (size_t)W, o_mat = o_row + 8 * ((size_t)W + 1);
-    const size_t total_bytes = o_mat + 8 * (size_t)W * ((size_t)W + 1);
+    const size_t RW = (size_t)W + kRowExtra;
+    // device scratch: own header | all headers | own row | row matrix (read back in one copy from o_hdrs on).  The one
+    // allocation in front of the first collective (a few KiB); everything after it is decided by all ranks together.
+    const size_t o_hdr = 0, o_hdrs = 32, o_row = o_hdrs + 32 * (size_t)W, o_mat = o_row + 8 * RW;
+    const size_t total_bytes = o_mat + 8 * (size_t)W * RW;
     CHK(dev_ensure(c, c->st_xchg, total_bytes));
     if (c->xchg_host_cap < total_bytes) {
         if (c->xchg_host) (void)hipHostFree(c->xchg_host);
@@ -1820,20 +1950,55 @@ extern "C" int o3dr_merge_partitioned(o3dr_ctx* c, void* nccl_comm, int32_t gath
         if (hipHostMalloc((void**)&c->xchg_host, total_bytes, hipHostMallocDefault) != hipSuccess) return fail(O3DR_ERR_ALLOC, "hipHostMalloc failed");
         c->xchg_host_cap = total_bytes;
     }
+    memset(c->xchg_stats, 0, sizeof c->xchg_stats);
     char* d = (char*)c->st_xchg.p;
-    // 1. headers; 2. partition against the box they span; 3. count matrix and the ONE read-back
-    CHK(o3dr_cloud_big_header_dev(c, d + o_hdr));
-    NCCLCHK(R, R->AllGather(d + o_hdr, d + o_hdrs, 32, ncclUint8, comm, c->stream));
-    CHK(o3dr_cloud_big_partition_dev(c, d + o_hdrs, W, W, (int64_t*)(d + o_row)));
-    NCCLCHK(R, R->AllGather(d + o_row, d + o_mat, (size_t)W + 1, ncclInt64, comm, c->stream));
-    HIPCHK(hipMemcpyAsync(c->xchg_host + o_hdrs, d + o_hdrs, total_bytes - o_hdrs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     struct Hdr {
         float mn[3], mx[3];
-        int64_t count;
+        int64_t count;  // negative: this rank's O3DR_ERR_* code
     };
+    int local = O3DR_OK;  // this rank's first failure; it keeps taking part in the collectives that remain
+    std::string local_msg;
+    auto note = [&](int rc) {
+        if (rc != O3DR_OK && local == O3DR_OK) {
+            local = rc;
+            local_msg = g_err;
+        }
+    };
+    auto injected = [&](int point) {  // o3dr_test_fail_at
+        if (c->test_fail_at != point) return false;
+        c->test_fail_at = 0;
+        (void)fail(O3DR_ERR_ALLOC, "failure injected by o3dr_test_fail_at");
+        return true;
+    };
+    // 1. headers
+    note(injected(1) ? O3DR_ERR_ALLOC : o3dr_cloud_big_header_dev(c, d + o_hdr));
+    if (local != O3DR_OK) {
+        Hdr* eh = (Hdr*)c->xchg_host;
+        for (int a = 0; a < 3; ++a) eh->mn[a] = __builtin_inff(), eh->mx[a] = -__builtin_inff();
+        eh->count = (int64_t)local;
+        HIPCHK(hipMemcpyAsync(d + o_hdr, eh, 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));  // (the pinned word is reused below)
+    }
+    CHK(T.all_gather(c, d + o_hdr, d + o_hdrs, 32));
+    // 2. partition against the box the headers span
+    if (local == O3DR_OK) note(injected(2) ? O3DR_ERR_ALLOC : o3dr_cloud_big_partition_dev(c, d + o_hdrs, W, W, (int64_t*)(d + o_row)));
+    if (local != O3DR_OK) HIPCHK(hipMemsetAsync(d + o_row, 0, 8 * ((size_t)W + 1), c->stream));
+    int64_t* extra = (int64_t*)c->xchg_host;
+    extra[0] = (int64_t)local;
+    extra[1] = c->cloud_alt_cap;
+    extra[2] = (int64_t)(c->st_merge.cap / sizeof(o3dr_point));
+    extra[3] = (int64_t)(c->st_gather.cap / sizeof(o3dr_point));
+    HIPCHK(hipMemcpyAsync(d + o_row + 8 * ((size_t)W + 1), extra, 8 * (kRowExtra - 1), hipMemcpyHostToDevice, c->stream));
+    // 3. row matrix and the ONE read-back
+    CHK(T.all_gather(c, d + o_row, d + o_mat, 8 * RW));
+    HIPCHK(hipMemcpyAsync(c->xchg_host + o_hdrs, d + o_hdrs, total_bytes - o_hdrs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     const Hdr* hdrs = (const Hdr*)(c->xchg_host + o_hdrs);
     const int64_t* mat = (const int64_t*)(c->xchg_host + o_mat);
+    for (int r = 0; r < W; ++r) {  // a failure anywhere so far: every rank sees it here and leaves before the all-to-all
+        const int64_t code = hdrs[r].count < 0 ? hdrs[r].count : mat[(size_t)r * RW + W + 1];
+        if (code < 0) return peer_error(local, r, code, local_msg);
+    }
     float gmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, gmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     int64_t total_pts = 0;
     for (int r = 0; r < W; ++r) {
@@ -1847,43 +2012,83 @@ extern "C" int o3dr_merge_partitioned(o3dr_ctx* c, void* nccl_comm, int32_t gath
     if (n_total) *n_total = total_pts;
     const int64_t n_local = hdrs[rank].count;
     bool overflow = false;
-    for (int r = 0; r < W; ++r) overflow = overflow || ((mat[(size_t)r * (W + 1) + W] & 1) != 0);  // (same global box everywhere: all agree)
+    for (int r = 0; r < W; ++r) overflow = overflow || ((mat[(size_t)r * RW + W] & 1) != 0);  // (same global box everywhere: all agree)
+    // what every rank sends, receives and merges (the same arithmetic on the same matrix everywhere)
+    auto sends = [&](int from, int to) { return overflow ? (from == to ? hdrs[from].count : (int64_t)0) : mat[(size_t)from * RW + to]; };
     std::vector<int64_t> send((size_t)W, 0), recv((size_t)W, 0), slice_in((size_t)W, 0);
     for (int p = 0; p < W; ++p) {
-        send[(size_t)p] = overflow ? (p == rank ? n_local : 0) : mat[(size_t)rank * (W + 1) + p];
-        recv[(size_t)p] = overflow ? (p == rank ? n_local : 0) : mat[(size_t)p * (W + 1) + rank];
-        for (int r = 0; r < W; ++r) slice_in[(size_t)p] += overflow ? (r == p ? hdrs[p].count : 0) : mat[(size_t)r * (W + 1) + p];
+        send[(size_t)p] = sends(rank, p);
+        recv[(size_t)p] = sends(p, rank);
+        for (int r = 0; r < W; ++r) slice_in[(size_t)p] += sends(r, p);
     }
     int64_t n_recv = 0, max_slice = 0;
     for (int p = 0; p < W; ++p) n_recv += recv[(size_t)p], max_slice = std::max(max_slice, slice_in[(size_t)p]);
     if (total_pts == 0) return O3DR_OK;
-    if (n_recv >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "a slice exceeds 2^32-1 points");
+    if (max_slice >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "a slice exceeds 2^32-1 points");  // (every rank: same matrix)
+    // an upper bound of any rank's merged slice, for the gather buffer: no more cells than points in the slice, and a
+    // slice covers at most ~cells / W linear indices of the combined grid over the global box (part_of: multiply-shift)
+    int64_t pad_bound = max_slice;
+    if (!overflow) {
+        float leaf[3], zo;
+        uint32_t mp;
+        downsample_leaf(c->params, 1, leaf, &mp, &zo);
+        double cells = 1.0;
+        const double lo[3] = {gmin[0], gmin[1], (double)gmin[2] + zo}, hi[3] = {gmax[0], gmax[1], (double)gmax[2] + zo};
+        for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / (double)leaf[a]) + 3.0;
+        const double per_slice = 2.0 * cells / W + 4.0;
+        if (per_slice < (double)pad_bound) pad_bound = (int64_t)per_slice;
+    }
+    c->xchg_stats[0] = n_local;
+    c->xchg_stats[1] = n_local - send[(size_t)rank];                                   // points sent to other ranks
+    c->xchg_stats[2] = n_recv - recv[(size_t)rank];                                    // points received from other ranks
+    c->xchg_stats[3] = c->xchg_stats[1] * (int64_t)sizeof(o3dr_point);                 // bytes sent over the links
+    c->xchg_stats[4] = c->xchg_stats[2] * (int64_t)sizeof(o3dr_point);
+    c->xchg_stats[5] = n_recv;                                                         // points entering this rank's merge
+    c->xchg_stats[7] = total_pts;
+    // does any rank have to grow a buffer before the all-to-all?  (every rank evaluates every rank: no disagreement)
+    bool any_grows = false;
+    for (int r = 0; r < W; ++r) {
+        int64_t nr = 0;
+        for (int p = 0; p < W; ++p) nr += sends(p, r);
+        const int64_t* ex = mat + (size_t)r * RW + W + 2;
+        any_grows = any_grows || (!overflow && nr > ex[0]) || max_slice > ex[1] || (gather_result && (int64_t)W * pad_bound > ex[2]);
+    }
+    if (any_grows) {
+        int rc = O3DR_OK;
+        if (injected(3)) rc = O3DR_ERR_ALLOC;
+        if (rc == O3DR_OK && !overflow) rc = alt_reserve(c, n_recv > 0 ? n_recv : 1);
+        if (rc == O3DR_OK) rc = dev_ensure(c, c->st_merge, (size_t)(max_slice > 0 ? max_slice : 1) * sizeof(o3dr_point));
+        if (rc == O3DR_OK && gather_result) rc = dev_ensure(c, c->st_gather, (size_t)W * (size_t)(pad_bound > 0 ? pad_bound : 1) * sizeof(o3dr_point));
+        note(rc);
+        extra[0] = (int64_t)local;
+        HIPCHK(hipMemcpyAsync(d + o_row, extra, 8, hipMemcpyHostToDevice, c->stream));
+        CHK(T.all_gather(c, d + o_row, d + o_mat, 8));
+        HIPCHK(hipMemcpyAsync(c->xchg_host + o_mat, d + o_mat, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->xchg_stats[6] = 1;  // agreement rounds of this call
+        for (int r = 0; r < W; ++r)
+            if (mat[r] < 0) return peer_error(local, r, mat[r], local_msg);
+    }
     c->cloud_ub = n_local;  // (its own header told the host)
     c->cloud_n_exact = true;
     if (!overflow) {
-        // all-to-all out of cloud_big into the second cloud buffer: every peer pair has its own xGMI link; segments land in
-        // source-rank order = global frame order
-        CHK(alt_reserve(c, n_recv > 0 ? n_recv : 1));
-        NCCLCHK(R, R->GroupStart());
-        int64_t soff = 0, roff = 0;
-        for (int p = 0; p < W; ++p) {
-            if (send[(size_t)p]) NCCLCHK(R, R->Send(c->cloud_big + soff, (size_t)send[(size_t)p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream));
-            if (recv[(size_t)p]) NCCLCHK(R, R->Recv(c->cloud_alt + roff, (size_t)recv[(size_t)p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream));
-            soff += send[(size_t)p];
-            roff += recv[(size_t)p];
-        }
-        NCCLCHK(R, R->GroupEnd());
+        // all-to-all out of cloud_big into the second cloud buffer; segments land in source-rank order = global frame order
+        CHK(T.all_to_all(c, c->cloud_big, send.data(), c->cloud_alt, recv.data()));
         CHK(o3dr_cloud_big_adopt(c, n_recv));
     }
-    // 4. local merge of the slice over the global box (the second host wait: its size)
-    CHK(dev_ensure(c, c->st_merge, (size_t)(max_slice > 0 ? max_slice : 1) * sizeof(o3dr_point)));
+    // 4. local merge of the slice over the global box (the second host wait: its size).  A failure here travels with
+    //    the merged sizes of the final gather, so that no rank waits in a collective the failed one never enters.
     int64_t m = 0;
     uint32_t st = 0;
-    if (n_recv > 0) CHK(finalize_impl(c, gmin, gmax, (o3dr_point*)c->st_merge.p, max_slice, &m, &st, O3DR_MEM_DEVICE));
+    if (n_recv > 0) note(injected(4) ? O3DR_ERR_ALLOC : finalize_impl(c, gmin, gmax, (o3dr_point*)c->st_merge.p, max_slice, &m, &st, O3DR_MEM_DEVICE));
     if (overflow) st |= O3DR_STATUS_VOXEL_OVERFLOW;
     if (status) *status = st;
     const hipMemcpyKind kind = mem == O3DR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (!gather_result) {
+    if (!gather_result) {  // (no collective follows: a local failure is this rank's alone)
+        if (local != O3DR_OK) {
+            g_err = local_msg;
+            return local;
+        }
         if (out_capacity > 0) {
             if (m > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
             if (m > 0) HIPCHK(hipMemcpyAsync(out, c->st_merge.p, (size_t)m * sizeof(o3dr_point), kind, c->stream));
@@ -1892,19 +2097,20 @@ extern "C" int o3dr_merge_partitioned(o3dr_ctx* c, void* nccl_comm, int32_t gath
         }
         return O3DR_OK;
     }
-    // 5. final gather: sizes, then the slices padded to the largest (rank order = ascending voxel index)
+    // 5. final gather: sizes (or error codes), then the slices padded to the largest (rank order = ascending voxel index)
     int64_t* mh = (int64_t*)c->xchg_host;
-    mh[0] = m;
+    mh[0] = local != O3DR_OK ? (int64_t)local : m;
     HIPCHK(hipMemcpyAsync(d + o_row, mh, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(R, R->AllGather(d + o_row, d + o_mat, 1, ncclInt64, comm, c->stream));
+    CHK(T.all_gather(c, d + o_row, d + o_mat, 8));
     HIPCHK(hipMemcpyAsync(c->xchg_host + o_mat, d + o_mat, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int64_t pad = 0, merged_total = 0;
-    for (int r = 0; r < W; ++r) pad = std::max(pad, mat[r]), merged_total += mat[r];
-    if (pad > 0) {
-        CHK(dev_ensure(c, c->st_gather, (size_t)W * (size_t)pad * sizeof(o3dr_point)));
-        NCCLCHK(R, R->AllGather(c->st_merge.p, c->st_gather.p, (size_t)pad * sizeof(o3dr_point), ncclUint8, comm, c->stream));
+    for (int r = 0; r < W; ++r) {
+        if (mat[r] < 0) return peer_error(local, r, mat[r], local_msg);
+        pad = std::max(pad, mat[r]), merged_total += mat[r];
     }
+    if (pad > pad_bound) return fail(O3DR_ERR_INTERNAL, "a merged slice exceeds its bound");  // (every rank: same sizes, same bound)
+    if (pad > 0) CHK(T.all_gather(c, c->st_merge.p, c->st_gather.p, (size_t)pad * sizeof(o3dr_point)));
     if (out_capacity > 0) {  // (a rank that does not want the result passes no buffer; it still took part in the collectives)
         if (merged_total > out_capacity) {
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -1922,17 +2128,107 @@ extern "C" int o3dr_merge_partitioned(o3dr_ctx* c, void* nccl_comm, int32_t gath
     return O3DR_OK;
 }
 
+extern "C" int o3dr_merge_partitioned(o3dr_ctx* c, void* nccl_comm, int32_t gather_result, o3dr_point* out, int64_t out_capacity,
+                                      int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem)
+{
+    if (n_out) *n_out = 0;
+    if (n_total) *n_total = 0;
+    if (status) *status = 0;
+    CTX_ENTER(c);
+    if (!nccl_comm || !n_out) return fail(O3DR_ERR_INVALID_ARG, "nccl_comm / n_out is NULL");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (out_capacity < 0 || (out_capacity > 0 && !out)) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
+    RcclTransport T;
+    T.R = rccl_api();
+    if (!T.R) return fail(O3DR_ERR_HIP, "RCCL (librccl.so.1) could not be loaded");
+    T.comm = (ncclComm_t)nccl_comm;
+    NCCLCHK(T.R, T.R->CommCount(T.comm, &T.W));
+    NCCLCHK(T.R, T.R->CommUserRank(T.comm, &T.rank));
+    return merge_partitioned_impl(c, T, gather_result, out, out_capacity, n_out, n_total, status, mem);
+}
+
+extern "C" int o3dr_merge_partitioned_stats(o3dr_ctx* c, int64_t out[8])
+{
+    CTX_ENTER(c);
+    if (!out) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
+    memcpy(out, c->xchg_stats, sizeof c->xchg_stats);
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_capacity(o3dr_ctx* c, int64_t* cloud_points, int64_t* recv_points)
+{
+    CTX_ENTER(c);
+    if (cloud_points) *cloud_points = c->cloud_cap;
+    if (recv_points) *recv_points = c->cloud_alt_cap;
+    return O3DR_OK;
+}
+
+// ---- test-only: the exchange among W contexts of one process (include/o3dr_testing.h) -----------------------------------
+extern "C" int o3dr_test_local_comm_create(int32_t n_ranks, void** comm_out)
+{
+    if (n_ranks < 1 || n_ranks > kMaxRadix || !comm_out) return fail(O3DR_ERR_INVALID_ARG, "bad arguments (1 <= n_ranks <= 128)");
+    LocalComm* L = new LocalComm;
+    L->W = n_ranks;
+    L->ptr.assign((size_t)n_ranks, nullptr);
+    L->cnt.assign((size_t)n_ranks, nullptr);
+    *comm_out = L;
+    return O3DR_OK;
+}
+extern "C" int o3dr_test_local_comm_destroy(void* comm)
+{
+    delete (LocalComm*)comm;
+    return O3DR_OK;
+}
+extern "C" int o3dr_test_merge_partitioned_local(o3dr_ctx* c, void* local_comm, int32_t rank, int32_t gather_result, o3dr_point* out,
+                                                 int64_t out_capacity, int64_t* n_out, int64_t* n_total, uint32_t* status, int32_t mem)
+{
+    if (n_out) *n_out = 0;
+    if (n_total) *n_total = 0;
+    if (status) *status = 0;
+    CTX_ENTER(c);
+    if (!c->test_hooks) return fail(O3DR_ERR_INVALID_ARG, "test hooks are off (create the context with O3DR_TEST_HOOKS=1)");
+    if (!local_comm || !n_out) return fail(O3DR_ERR_INVALID_ARG, "local_comm / n_out is NULL");
+    if (mem != O3DR_MEM_HOST && mem != O3DR_MEM_DEVICE) return fail(O3DR_ERR_INVALID_ARG, "bad mem kind");
+    if (out_capacity < 0 || (out_capacity > 0 && !out)) return fail(O3DR_ERR_INVALID_ARG, "out is NULL");
+    LocalTransport T;
+    T.L = (LocalComm*)local_comm;
+    T.W = T.L->W;
+    T.rank = rank;
+    return merge_partitioned_impl(c, T, gather_result, out, out_capacity, n_out, n_total, status, mem);
+}
+extern "C" int o3dr_test_fail_at(o3dr_ctx* c, int32_t point)
+{
+    CTX_ENTER(c);
+    if (!c->test_hooks) return fail(O3DR_ERR_INVALID_ARG, "test hooks are off (create the context with O3DR_TEST_HOOKS=1)");
+    c->test_fail_at = point;
+    return O3DR_OK;
+}
+
 // page-locking of caller memory (frame stacks handed to o3dr_accumulate_frames with O3DR_MEM_HOST then move by DMA)
 extern "C" int o3dr_host_register(void* ptr, int64_t bytes)
 {
     if (!ptr || bytes <= 0) return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
-    HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    // (callers treat this as best effort: HIP's sticky last error must not outlive the failure, or the next
+    // hipGetLastError() after a kernel launch would report it as that launch's)
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        char buf[256];
+        snprintf(buf, sizeof buf, "hipHostRegister failed: %s", hipGetErrorString(e));
+        return fail(O3DR_ERR_HIP, buf);
+    }
     return O3DR_OK;
 }
 extern "C" int o3dr_host_unregister(void* ptr)
 {
     if (!ptr) return O3DR_OK;
-    HIPCHK(hipHostUnregister(ptr));
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        char buf[256];
+        snprintf(buf, sizeof buf, "hipHostUnregister failed: %s", hipGetErrorString(e));
+        return fail(O3DR_ERR_HIP, buf);
+    }
     return O3DR_OK;
 }
 

@@ -88,6 +88,25 @@ def _parse_headers(raw, world):
     return boxes[live, 0:3].min(axis=0).astype(np.float32), boxes[live, 3:6].max(axis=0).astype(np.float32), counts
 
 
+class ExchangeError(RuntimeError):
+    """merge_partitioned failed on some rank; EVERY rank raises at the same point of the protocol (`rank` = the first
+    rank that reported a failure, `code` = its negative error code, `own` = it was this rank)."""
+
+    def __init__(self, rank, code, own, text=""):
+        super().__init__(f"merge_partitioned: rank {rank} failed with code {code}; every rank left the exchange together"
+                         + (f" ({text})" if text else ""))
+        self.rank, self.code, self.own = rank, code, own
+
+
+_I64_MAX = (1 << 63) - 1
+_ROW_EXTRA = 5  # status | this rank's error code | receive-buffer capacity | (merge, gather buffers: torch's here)
+
+
+def _err_code(e):
+    c = getattr(e, "code", None)
+    return int(c) if isinstance(c, int) and c < 0 else -3
+
+
 def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=None):
     """The reference's final merge (pose.cpp:530) over frames sharded across ranks, without replicating it:
 
@@ -106,15 +125,33 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
     methods (CPU stand-ins in the gloo tests) and rehearsals with `comm_device` (collectives on host copies) run the
     same protocol on host values.
 
+    FAILURE IS COLLECTIVE (the same wire format as o3dr_merge_partitioned, include/o3dr.h): a rank whose own step raises
+    keeps taking part in the collectives that remain, with its error code in place of its data - a negative count in its
+    header, a word next to its slice counts, a negative merged size - and every rank raises ExchangeError at the same point.
+    The receive buffer's capacity travels with the slice counts: only when some rank has to grow it (known to all) does
+    one more 8-byte all-gather carry the outcome of that allocation before the all-to-all.
+
     Returns (merged [M,4] int32 tensor or this rank's slice if gather_result is False, total points merged).
-    Bit-identical to a single-GPU run over all frames."""
+    Bit-identical to a single-GPU run over all frames.  `last_stats` holds what this call did and moved."""
     import numpy as np
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     cdev = comm_device if comm_device is not None else device
     on_gpu = torch.device(device).type == "cuda"
     dev_path = comm_device is None and hasattr(ctx, "cloudBigPartitionDev")
-    stats = {"collectives": 0, "host_syncs_before_final_gather": 0, "device_resident": bool(dev_path)}
+    stats = {"collectives": 0, "host_syncs_before_final_gather": 0, "device_resident": bool(dev_path), "agreement_rounds": 0}
+    RW = world + _ROW_EXTRA
+    local = {"code": 0, "text": ""}
+
+    def note(e):
+        if local["code"] == 0:
+            local["code"], local["text"] = _err_code(e), repr(e)
+
+    def leave(first_rank, code):
+        last_stats.clear()
+        last_stats.update(stats)
+        raise ExchangeError(first_rank, int(code), local["code"] != 0, local["text"])
+
     # Stream order: the library works on the context's stream, torch's collectives are ordered against torch's current
     # stream.  When the two are the same stream (bench.py hands the context torch's), nothing else is needed; else the
     # host drains one for the other (counted below).
@@ -132,59 +169,105 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
             stats["host_syncs_before_final_gather"] += 1
 
     # 1. headers
-    mine_hdr = _header_tensor(ctx, cdev, dev_path)
+    try:
+        mine_hdr = _header_tensor(ctx, cdev, dev_path)
+    except Exception as e:  # noqa: BLE001 - whatever it is, the peers must not be left inside the all-gather
+        note(e)
+        raw = np.concatenate([np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)]).tobytes() + np.int64(local["code"]).tobytes()
+        mine_hdr = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(cdev)
     if not dev_path:
         stats["host_syncs_before_final_gather"] += 1  # (host values: the box and count were read back)
     lib_to_torch()
     hdrs = torch.empty(world * 32, dtype=torch.uint8, device=cdev)
     dist.all_gather_into_tensor(hdrs, mine_hdr, group=group)
     stats["collectives"] += 1
-    # 2. partition (+ status word)
+    # 2. partition (+ status word, this rank's error code, its receive buffer's capacity)
+    row_head = None
     if dev_path:
         torch_to_lib()
-        row = ctx.cloudBigPartitionDev(hdrs, world)       # int64 [world + 1] in HBM, asynchronous
+        if local["code"] == 0:
+            try:
+                row_head = ctx.cloudBigPartitionDev(hdrs, world)  # int64 [world + 1] in HBM, asynchronous
+            except Exception as e:  # noqa: BLE001
+                note(e)
         lib_to_torch()
     else:
         gmin, gmax, hcounts = _parse_headers(hdrs.cpu().numpy(), world)
+        if (hcounts < 0).any():  # (host values: every rank sees the failed header here)
+            bad = int(np.nonzero(hcounts < 0)[0][0])
+            leave(bad, hcounts[bad])
         if int(hcounts.sum()) == 0:
             last_stats.clear()
             last_stats.update(stats)
             return torch.empty((0, 4), dtype=torch.int32, device=device), 0
-        counts, status = ctx.cloudBigPartition(gmin, gmax, world)
+        try:
+            counts, status = ctx.cloudBigPartition(gmin, gmax, world)
+            row_head = torch.tensor(list(counts) + [int(status)], dtype=torch.int64, device=cdev)
+        except Exception as e:  # noqa: BLE001
+            note(e)
         stats["host_syncs_before_final_gather"] += 1
-        row = torch.tensor(list(counts) + [int(status)], dtype=torch.int64, device=cdev)
-    # 3. count matrix, the one read-back, the all-to-all
-    matrix = torch.empty(world * (world + 1), dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(matrix, row, group=group)   # row s = what rank s sends to everybody (+ its status)
+    if row_head is None:
+        row_head = torch.zeros(world + 1, dtype=torch.int64, device=cdev)
+    zero_copy = comm_device is None and hasattr(ctx, "cloudBigView")
+    recv_cap = ctx.cloudBigCapacity()[1] if (zero_copy and hasattr(ctx, "cloudBigCapacity")) else (0 if zero_copy else _I64_MAX)
+    row = torch.cat([row_head, torch.tensor([local["code"], recv_cap, _I64_MAX, _I64_MAX], dtype=torch.int64).to(cdev)])
+    # 3. row matrix, the one read-back, the all-to-all
+    matrix = torch.empty(world * RW, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(matrix, row, group=group)   # row s = what rank s sends to everybody (+ its status words)
     stats["collectives"] += 1
     both = torch.cat([hdrs.view(torch.int64), matrix]).cpu().numpy()  # headers + matrix: ONE blocking copy
     hdrs_h = both[: world * 4].view(np.uint8)
-    matrix_h = both[world * 4:].reshape(world, world + 1)
+    matrix_h = both[world * 4:].reshape(world, RW)
     if dev_path:
         stats["host_syncs_before_final_gather"] += 1
     gmin, gmax, hcounts = _parse_headers(hdrs_h, world)
+    for r in range(world):  # a failure anywhere so far: every rank sees it here and leaves before the all-to-all
+        code = int(hcounts[r]) if hcounts[r] < 0 else int(matrix_h[r, world + 1])
+        if code < 0:
+            leave(r, code)
     total = int(hcounts.sum())
     n_local = int(hcounts[rank])
     if total == 0:
         last_stats.clear()
         last_stats.update(stats)
         return torch.empty((0, 4), dtype=torch.int32, device=device), 0
-    counts = [int(v) for v in matrix_h[rank, :world]]
     overflow = bool((matrix_h[:, world] & 1).any())         # (the same global box on every rank: all agree)
     if overflow:  # PCL's overflow guard on the global box: the merge returns its input unchanged
-        counts = [0] * world
-        counts[rank] = n_local  # everything stays where it is; rank order is already global order
-        recv_counts = list(counts)
+        sends = np.diag(hcounts.astype(np.int64))           # everything stays where it is; rank order is already global order
     else:
-        recv_counts = [int(v) for v in matrix_h[:, rank]]
+        sends = matrix_h[:, :world].astype(np.int64)        # sends[s, r] = points rank s sends to rank r
+    counts = [int(v) for v in sends[rank]]
+    recv_counts = [int(v) for v in sends[:, rank]]
     n_recv = sum(recv_counts)
-    zero_copy = comm_device is None and hasattr(ctx, "cloudBigView")
+    stats.update({"points_local": n_local, "points_sent_off_rank": n_local - counts[rank],
+                  "points_received_off_rank": n_recv - recv_counts[rank], "bytes_sent": 16 * (n_local - counts[rank]),
+                  "bytes_received": 16 * (n_recv - recv_counts[rank]), "points_into_merge": n_recv, "points_all_ranks": total})
+    # does any rank have to grow its receive buffer?  (every rank evaluates every rank: no disagreement)
+    any_grows = bool((sends.sum(axis=0) > matrix_h[:, world + 2]).any()) and not overflow
+    recv = None
+    if any_grows:
+        if zero_copy:
+            try:
+                recv = ctx.cloudBigRecvBuffer(n_recv)
+            except Exception as e:  # noqa: BLE001
+                note(e)
+        ok = torch.empty(world, dtype=torch.int64, device=cdev)
+        lib_to_torch()
+        dist.all_gather_into_tensor(ok, torch.tensor([local["code"]], dtype=torch.int64).to(cdev), group=group)
+        stats["collectives"] += 1
+        stats["agreement_rounds"] = 1
+        ok_h = ok.cpu().numpy()
+        stats["host_syncs_before_final_gather"] += 1
+        for r in range(world):
+            if ok_h[r] < 0:
+                leave(r, ok_h[r])
     if zero_copy:
         # send straight out of cloud_big, receive straight into the library's second cloud buffer
         if hasattr(ctx, "cloudBigAssumeSize"):
             ctx.cloudBigAssumeSize(n_local)                 # (its own header told the host: no round trip for the view)
         send = ctx.cloudBigView()
-        recv = ctx.cloudBigRecvBuffer(n_recv)
+        if recv is None:
+            recv = ctx.cloudBigRecvBuffer(n_recv)           # (fits: every rank checked every rank's capacity)
         lib_to_torch()
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
         stats["collectives"] += 1
@@ -198,18 +281,37 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
         ctx.cloudBigReset()
         if recv.shape[0]:
             ctx.cloudBigAppend(recv.to(device))
-    # 4. local merge of the slice (the round trip for its size is inside)
-    if dev_path:
-        mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax, n_hint=n_recv)
-    else:
-        mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax)
+    # 4. local merge of the slice (the round trip for its size is inside).  A failure here travels with the merged sizes
+    #    of the final gather, so that no rank waits in a collective the failed one never enters.
+    mine = None
+    try:
+        if dev_path:
+            mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax, n_hint=n_recv)
+        else:
+            mine = ctx.finalize(device=device, gmin=gmin, gmax=gmax)
+    except Exception as e:  # noqa: BLE001
+        note(e)
     stats["host_syncs_before_final_gather"] += 1
     last_stats.clear()
     last_stats.update(stats)
-    if not gather_result:
+    if not gather_result:  # (no collective follows: a local failure is this rank's alone)
+        if local["code"]:
+            leave(rank, local["code"])
         return mine, total
-    # 5. final gather (sizes, then the padded slices)
+    # 5. final gather: sizes (or error codes), then the slices padded to the largest
     lib_to_torch()
-    shards, _ = all_gather_points(mine.to(cdev), group)
-    last_stats["collectives"] += 2
-    return torch.cat(shards).to(device), total
+    n_mine = local["code"] if local["code"] else int(mine.shape[0])
+    sizes = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([n_mine], dtype=torch.int64).to(cdev), group=group)
+    last_stats["collectives"] += 1
+    sizes_h = [int(v) for v in sizes.tolist()]
+    for r in range(world):
+        if sizes_h[r] < 0:
+            leave(r, sizes_h[r])
+    m = max(max(sizes_h), 1)
+    padded = torch.empty((m, 4), dtype=torch.int32, device=cdev)
+    padded[: mine.shape[0]] = mine.to(cdev)
+    gathered = torch.empty((world * m, 4), dtype=torch.int32, device=cdev)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    last_stats["collectives"] += 1
+    return torch.cat([gathered[r * m: r * m + sizes_h[r]] for r in range(world)]).to(device), total

@@ -559,14 +559,15 @@ void Pose::run_reconstruction()
                 cout << " " << im.raw_img_data_ptr->img_num << flush;
             }
             // page-locked frame stacks cross PCIe by DMA (best effort: pageable memory works too)
-            (void)o3dr_host_register(disp.data(), (int64_t)disp.size());
-            (void)o3dr_host_register(bgr.data(), (int64_t)bgr.size());
-            chk(o3dr_accumulate_frames_kp(c, disp.data(), (int64_t)dsz, cols, bgr.data(), (int64_t)csz, 3 * (int64_t)cols, rows,
-                                          cols, poses.data(), (int32_t)n_acc, kp_xy.empty() ? nullptr : kp_xy.data(),
-                                          kp_xy.empty() ? nullptr : kp_off.data(), O3DR_MEM_HOST),
-                "accumulate_frames");
-            (void)o3dr_host_unregister(disp.data());
-            (void)o3dr_host_unregister(bgr.data());
+            const bool reg_disp = o3dr_host_register(disp.data(), (int64_t)disp.size()) == O3DR_OK;
+            const bool reg_bgr = o3dr_host_register(bgr.data(), (int64_t)bgr.size()) == O3DR_OK;
+            const int rc_acc = o3dr_accumulate_frames_kp(c, disp.data(), (int64_t)dsz, cols, bgr.data(), (int64_t)csz, 3 * (int64_t)cols, rows,
+                                                         cols, poses.data(), (int32_t)n_acc, kp_xy.empty() ? nullptr : kp_xy.data(),
+                                                         kp_xy.empty() ? nullptr : kp_off.data(), O3DR_MEM_HOST);
+            const string why_acc = rc_acc != O3DR_OK ? o3dr_last_error() : "";
+            if (reg_disp) (void)o3dr_host_unregister(disp.data());  // (only what was registered; also on the error path)
+            if (reg_bgr) (void)o3dr_host_unregister(bgr.data());
+            if (rc_acc != O3DR_OK) throw runtime_error("accumulate_frames: " + why_acc);
         }
         chk(o3dr_ctx_synchronize(c), "synchronize");
         const double dt = chrono::duration<double>(clk::now() - t3).count();
@@ -624,8 +625,9 @@ void Pose::run_sharded(PointCloud::Ptr cloud_small)
         kp_xy.insert(kp_xy.end(), im.keypoints_xy.begin(), im.keypoints_xy.end());
         kp_off[k + 1] = (int64_t)(kp_xy.size() / 2);
     }
-    (void)o3dr_host_register(disp.data(), (int64_t)disp.size());
-    (void)o3dr_host_register(bgr.data(), (int64_t)bgr.size());
+    // (best effort: pageable memory works too, through the runtime's bounce buffers; only what was registered is released)
+    const bool reg_disp = o3dr_host_register(disp.data(), (int64_t)disp.size()) == O3DR_OK;
+    const bool reg_bgr = o3dr_host_register(bgr.data(), (int64_t)bgr.size()) == O3DR_OK;
     const int W = n_gpus;
     vector<int32_t> devs((size_t)W);
     for (int g = 0; g < W; ++g) devs[(size_t)g] = device_id + g;
@@ -638,12 +640,25 @@ void Pose::run_sharded(PointCloud::Ptr cloud_small)
     vector<string> errors((size_t)W);
     vector<int64_t> n_out((size_t)W, 0), n_total((size_t)W, 0);
     vector<uint32_t> st((size_t)W, 0);
+    // Every rank's context exists before any rank starts: a rank without one could never enter the exchange, and its
+    // peers would wait for it inside the first collective.  Past this point a failure on one rank is carried through the
+    // collectives by o3dr_merge_partitioned itself (every rank returns together).
+    vector<o3dr_ctx*> ctxs((size_t)W, nullptr);
+    for (int g = 0; g < W; ++g) {
+        if (o3dr_ctx_create(devs[(size_t)g], &ctxs[(size_t)g]) != O3DR_OK) {
+            const string why = o3dr_last_error();
+            for (int k = 0; k < g; ++k) (void)o3dr_ctx_destroy(ctxs[(size_t)k]);
+            for (int k = 0; k < W; ++k) (void)o3dr_comm_destroy(comms[(size_t)k]);
+            if (reg_disp) (void)o3dr_host_unregister(disp.data());
+            if (reg_bgr) (void)o3dr_host_unregister(bgr.data());
+            throw runtime_error("GPU " + to_string(devs[(size_t)g]) + ": o3dr_ctx_create: " + why);
+        }
+    }
     vector<thread> th;
     for (int g = 0; g < W; ++g) {
         th.emplace_back([&, g]() {
-            o3dr_ctx* c = nullptr;
+            o3dr_ctx* c = ctxs[(size_t)g];
             try {
-                chk(o3dr_ctx_create(devs[(size_t)g], &c), "o3dr_ctx_create");
                 push_params(c);
                 const size_t base = n_acc / (size_t)W, rem = n_acc % (size_t)W;  // contiguous blocks (dist.shard_range)
                 const size_t a = (size_t)g * base + min<size_t>((size_t)g, rem), b = a + base + ((size_t)g < rem ? 1 : 0);
@@ -667,8 +682,8 @@ void Pose::run_sharded(PointCloud::Ptr cloud_small)
     }
     for (thread& t : th) t.join();
     for (int g = 0; g < W; ++g) (void)o3dr_comm_destroy(comms[(size_t)g]);
-    (void)o3dr_host_unregister(disp.data());
-    (void)o3dr_host_unregister(bgr.data());
+    if (reg_disp) (void)o3dr_host_unregister(disp.data());
+    if (reg_bgr) (void)o3dr_host_unregister(bgr.data());
     for (int g = 0; g < W; ++g)
         if (!errors[(size_t)g].empty()) throw runtime_error("GPU " + to_string(devs[(size_t)g]) + ": " + errors[(size_t)g]);
     cloud_small->points.resize((size_t)n_out[0]);

@@ -131,6 +131,11 @@ class CpuCtxZeroCopy(CpuCtx):
     """+ the zero-copy plumbing of the real context (o3dr_cloud_big_view / _recv_buffer / _adopt): the send buffer IS
     the cloud, the receive buffer belongs to the context, adopt makes its first n points the new cloud"""
 
+    recv_cap = 1 << 40  # points the receive buffer "holds" (a warmed-up context: nothing has to grow)
+
+    def cloudBigCapacity(self):
+        return len(self.cloud), self.recv_cap
+
     def cloudBigView(self):
         self._send = torch.from_numpy(self.cloud.view(np.int32).reshape(-1, 4))  # aliases the cloud: no copy
         return self._send
@@ -169,6 +174,40 @@ class CpuCtxDev(CpuCtxZeroCopy):
         return super().finalize(device, gmin, gmax)
 
 
+class CpuCtxCold(CpuCtxDev):
+    """a context whose receive buffer has to grow on this call (the first exchange of a run)"""
+    recv_cap = 0
+
+
+class Boom(RuntimeError):
+    code = -6  # O3DR_ERR_ALLOC
+
+
+class CpuCtxFailing(CpuCtxCold):
+    """raises at one step of the exchange, like a failed allocation inside the library would"""
+    fail_at = None
+
+    def cloudBigHeaderDev(self):
+        if self.fail_at == "header":
+            raise Boom("header")
+        return super().cloudBigHeaderDev()
+
+    def cloudBigPartitionDev(self, hdrs, n_parts):
+        if self.fail_at == "partition":
+            raise Boom("partition")
+        return super().cloudBigPartitionDev(hdrs, n_parts)
+
+    def cloudBigRecvBuffer(self, n_points):
+        if self.fail_at == "recv_buffer":
+            raise Boom("recv_buffer")
+        return super().cloudBigRecvBuffer(n_points)
+
+    def finalize(self, device=None, gmin=None, gmax=None, n_hint=None):
+        if self.fail_at == "finalize":
+            raise Boom("finalize")
+        return super().finalize(device, gmin, gmax, n_hint)
+
+
 def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
     import sys
     sys.path.insert(0, ROOT)
@@ -182,7 +221,7 @@ def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
     F_total, rows, cols, jump, vs = 7, 240, 400, 2, 0.05
     Q = synth.camera_Q(rows, cols)
     a, b = o3dist.shard_range(F_total, rank, world)
-    ctx = {False: CpuCtx, True: CpuCtxZeroCopy, "dev": CpuCtxDev}[zero_copy](orc, vs)
+    ctx = {False: CpuCtx, True: CpuCtxZeroCopy, "dev": CpuCtxDev, "cold": CpuCtxCold}[zero_copy](orc, vs)
     for i in range(a, b):
         d, c = synth.make_frame(i, rows, cols)
         ctx.cloud = np.concatenate([ctx.cloud, orc.create_and_transform_pt_cloud(d, c, Q, synth.make_pose(i), vs, jump_pixels=jump)[0]])
@@ -191,8 +230,16 @@ def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
     st = o3dist.last_stats
     # 5 collectives in all (headers, slice counts, all-to-all, merged sizes, merged slices); with the device-resident
     # small data the host waits twice before the final gather: for the count matrix and for the merged slice's size
-    assert st["collectives"] == 5 and st["device_resident"] == (zero_copy == "dev")
-    assert st["host_syncs_before_final_gather"] == (2 if zero_copy == "dev" else 3), st
+    # (a context whose receive buffer must grow - "cold" - adds the 8-byte agreement all-gather and its read-back)
+    cold = zero_copy == "cold"
+    assert st["collectives"] == (6 if cold else 5) and st["device_resident"] == (zero_copy in ("dev", "cold"))
+    assert st["agreement_rounds"] == (1 if cold else 0)
+    assert st["host_syncs_before_final_gather"] == {False: 3, True: 3, "dev": 2, "cold": 3}[zero_copy], st
+    # what the exchange moved: every point of this rank either stayed or was sent; what entered the merge is what arrived
+    assert st["points_local"] == n_before and 0 <= st["points_sent_off_rank"] <= n_before
+    assert st["bytes_sent"] == 16 * st["points_sent_off_rank"] and st["bytes_received"] == 16 * st["points_received_off_rank"]
+    assert st["points_into_merge"] == n_before - st["points_sent_off_rank"] + st["points_received_off_rank"]
+    assert st["points_all_ranks"] == total
     if zero_copy:  # counts matrix -> receive counts: what arrived is this rank's slice of everybody's cloud
         sent = torch.tensor([n_before], dtype=torch.int64)
         got = torch.tensor([len(ctx.cloud)], dtype=torch.int64)
@@ -207,7 +254,7 @@ def _worker_partitioned(rank, world, port, out_dir, zero_copy=False):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("zero_copy", [False, True, "dev"])
+@pytest.mark.parametrize("zero_copy", [False, True, "dev", "cold"])
 def test_partitioned_merge_equals_single_process(tmp_path, orc, zero_copy):
     """3 ranks, 7 frames: slices exchanged all-to-all, merged locally, gathered == one-process merge; with the copying
     exchange (what a rehearsal over gloo uses) and with the zero-copy one the GPU path takes (send view, library-owned
@@ -228,3 +275,54 @@ def test_partitioned_merge_equals_single_process(tmp_path, orc, zero_copy):
         got = np.load(tmp_path / f"merged_{r}.npy")
         assert int(np.load(tmp_path / f"total_{r}.npy")[0]) == len(big)
         assert len(got) == len(small) and np.array_equal(got.view(np.uint32), small.view(np.uint32))
+
+
+def _worker_failing(rank, world, port, out_dir, fail_at, fail_rank):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from online_3d_reconstruction_amd import dist as o3dist
+    from online_3d_reconstruction_amd import synth
+    from oracle import orc
+    rows, cols, jump, vs = 240, 400, 4, 0.05
+    Q = synth.camera_Q(rows, cols)
+    ctx = CpuCtxFailing(orc, vs)
+    d, c = synth.make_frame(rank, rows, cols)
+    ctx.cloud = orc.create_and_transform_pt_cloud(d, c, Q, synth.make_pose(rank), vs, jump_pixels=jump)[0]
+    n_before = len(ctx.cloud)
+    if rank == fail_rank:
+        ctx.fail_at = fail_at
+    try:
+        o3dist.merge_partitioned(ctx, torch.device("cpu"))
+        outcome = ("returned", -1, 0, False)
+    except o3dist.ExchangeError as e:
+        outcome = ("raised", e.rank, e.code, e.own)
+    # the process group is still usable: no rank is stuck inside a collective of the exchange
+    t = torch.tensor([1], dtype=torch.int64)
+    dist.all_reduce(t)
+    assert int(t) == world
+    # ... and a second exchange, with nothing failing, goes through (finalize failures come after the all-to-all: the
+    # clouds were exchanged by then, so only the count of all points is checked)
+    ctx.fail_at = None
+    merged, total = o3dist.merge_partitioned(ctx, torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"outcome_{rank}.npy"), np.array([outcome[0] == "raised", outcome[1], outcome[2], outcome[3], total, n_before, len(merged)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_at", ["header", "partition", "recv_buffer", "finalize"])
+def test_partitioned_merge_failure_on_one_rank_is_collective(tmp_path, fail_at):
+    """A rank whose own step fails must not leave its peers inside a collective: every rank raises
+    ExchangeError naming the failing rank and its code, at the same point of the protocol; the process group stays
+    usable and the next exchange succeeds."""
+    world, fail_rank = 3, 1
+    mp.spawn(_worker_failing, args=(world, _free_port(), str(tmp_path), fail_at, fail_rank), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"outcome_{r}.npy") for r in range(world)]
+    for r in range(world):
+        raised, bad_rank, code, own, total, n_before, n_merged = (int(v) for v in outs[r])
+        assert raised == 1 and bad_rank == fail_rank and code == -6 and own == int(r == fail_rank)
+        assert n_merged > 0
+    assert len({int(o[4]) for o in outs}) == 1 and int(outs[0][4]) == sum(int(o[5]) for o in outs)

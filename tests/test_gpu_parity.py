@@ -470,6 +470,126 @@ def test_partitioned_merge_virtual_ranks(Q, orc, world):
     assert min(sizes) > 0  # every slice got work
 
 
+def _local_exchange(Qs, disp, bgr, poses, prm, world, fail=None, gather=True):
+    """o3dr_merge_partitioned's own code with `world` ranks on one GPU: one context and one host thread per rank, joined
+    by the test-only LOCAL transport (include/o3dr_testing.h) instead of RCCL, which refuses two ranks on one device.
+    fail = (rank, point): o3dr_test_fail_at on that rank before the first exchange; the exchange is then run a second
+    time with nothing failing.  Returns per rank [(rc, n_out, n_total, status, stats, out)] per exchange."""
+    import ctypes as C
+    import threading
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import _lib as L
+    from online_3d_reconstruction_amd.dist import shard_range
+    lib = L.load_library()
+    F = len(disp)
+    comm = C.c_void_p()
+    assert lib.o3dr_test_local_comm_create(world, C.byref(comm)) == 0
+    ctxs = [o3dr.Context(0, Q=Qs, params=prm) for _ in range(world)]
+    results = [[] for _ in range(world)]
+    cap = int(sum(c.max_points(disp.shape[1], disp.shape[2]) for c in ctxs[:1])) * F + 1
+    try:
+        for r, c in enumerate(ctxs):
+            a, b = shard_range(F, r, world)
+            if b > a:
+                c.accumulateFrames(disp[a:b], bgr[a:b], poses[a:b])
+        if fail is not None:
+            assert lib.o3dr_test_fail_at(ctxs[fail[0]]._h, fail[1]) == 0
+
+        def run(r):
+            out = np.empty(cap, o3dr.POINT)
+            n, tot, st = C.c_int64(0), C.c_int64(0), C.c_uint32(0)
+            rc = lib.o3dr_test_merge_partitioned_local(ctxs[r]._h, comm, r, int(gather), out.ctypes.data, cap, C.byref(n), C.byref(tot),
+                                                       C.byref(st), L.MEM_HOST)
+            err = lib.o3dr_last_error().decode(errors="replace") if rc else ""
+            results[r].append((rc, n.value, tot.value, st.value, ctxs[r].mergePartitionedStats(), out[: n.value].copy(), err))
+
+        for _round in range(2 if fail is not None else 1):
+            th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(120)
+            assert not any(t.is_alive() for t in th), "a rank is stuck inside the exchange"
+    finally:
+        for c in ctxs:
+            c.close()
+        lib.o3dr_test_local_comm_destroy(comm)
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_merge_partitioned_entry_point_with_local_ranks(Q, orc, world, monkeypatch):
+    """The C entry point's own protocol code (headers, partition, count matrix, all-to-all, merge, final gather) with
+    W > 1 ranks: every rank returns the single-context merged cloud, bit for bit, and the oracle's; the statistics add
+    up (what is sent off-rank somewhere is received off-rank somewhere else)."""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    monkeypatch.setenv("O3DR_TEST_HOOKS", "1")
+    F = 12
+    disp, bgr = synth.make_frames(500, F, invalid_frac=0.01)
+    poses = synth.make_poses(500, F)
+    prm = _params(jump_pixels=3, voxel_size=0.05)
+    with o3dr.Context(0, Q=synth.camera_Q(), params=prm) as one:
+        one.accumulateFrames(disp, bgr, poses)
+        n_big = one.cloudBigSize()[0]
+        ref = one.finalize()
+    res = _local_exchange(synth.camera_Q(), disp, bgr, poses, prm, world)
+    sent = recv = local = into = 0
+    for r in range(world):
+        rc, n, tot, st, stats, out, err = res[r][0]
+        assert rc == 0, err
+        assert tot == n_big and st == 0
+        assert_points_equal(out, ref, f"o3dr_merge_partitioned over the local transport, rank {r} of {world}")
+        assert stats["points_all_ranks"] == n_big and stats["agreement_rounds"] == 1  # (first exchange: buffers grow)
+        assert stats["bytes_sent"] == 16 * stats["points_sent_off_rank"]
+        sent += stats["points_sent_off_rank"]
+        recv += stats["points_received_off_rank"]
+        local += stats["points_local"]
+        into += stats["points_into_merge"]
+    assert sent == recv and local == into == n_big and sent > 0
+    _, rsmall = orc.run_frames(disp, bgr, synth.camera_Q(), poses, 0.05, jump_pixels=3, threads=4)
+    assert_points_equal(res[0][0][5], rsmall, "o3dr_merge_partitioned over the local transport vs the oracle")
+
+
+@pytest.mark.parametrize("point", [1, 2, 3, 4])
+@pytest.mark.parametrize("gather", [True, False])
+def test_merge_partitioned_failure_on_one_rank_is_collective(Q, point, gather, monkeypatch):
+    """a rank whose own step fails (1 header, 2 partition, 3 an allocation before the all-to-all, 4 the
+    local merge) must not leave its peers inside a collective.  The failing rank returns its own code, every other rank
+    O3DR_ERR_PEER, nobody hangs; the contexts stay usable and a second exchange returns the right cloud on every rank.
+    (Without the final gather a failed local merge is that rank's alone.)"""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import _lib as L
+    from online_3d_reconstruction_amd import synth
+    monkeypatch.setenv("O3DR_TEST_HOOKS", "1")
+    world, bad, F = 3, 1, 6
+    disp, bgr = synth.make_frames(520, F, invalid_frac=0.01)
+    poses = synth.make_poses(520, F)
+    prm = _params(jump_pixels=4, voxel_size=0.05)
+    with o3dr.Context(0, Q=synth.camera_Q(), params=prm) as one:
+        one.accumulateFrames(disp, bgr, poses)
+        ref = one.finalize()
+    res = _local_exchange(synth.camera_Q(), disp, bgr, poses, prm, world, fail=(bad, point), gather=gather)
+    for r in range(world):
+        rc, n, tot, st, stats, out, err = res[r][0]
+        if point == 4 and not gather:
+            assert rc == (L.ERR_ALLOC if r == bad else 0), (r, rc, err)
+        else:
+            assert rc == (L.ERR_ALLOC if r == bad else L.ERR_PEER), (r, rc, err)
+            assert n == 0
+            assert ("rank %d" % bad in err) or r == bad, err
+    got = []
+    for r in range(world):
+        rc, n, tot, st, stats, out, err = res[r][1]
+        assert rc == 0, err
+        got.append(out)
+    if gather:
+        for r in range(world):
+            assert_points_equal(got[r], ref, f"second exchange after an injected failure at step {point}, rank {r}")
+    else:  # slices in rank order = the merged cloud
+        assert_points_equal(np.concatenate(got), ref, f"second exchange (slices) after an injected failure at step {point}")
+
+
 @pytest.mark.parametrize("shape", ["config3_dense_720p", "config5_4k_jump4"])
 def test_partitioned_merge_world8_config_shapes(orc, shape):
     """BASELINE configs[2] and configs[4] shapes through the 8-rank partitioned merge (8 virtual ranks on one GPU, two
@@ -617,6 +737,15 @@ def test_A3b_sor_mean_distances_bit_exact(orc, Q, frame_1248, monkeypatch):
     line = np.zeros(4000, orc.POINT)
     line["x"] = np.linspace(0, 1, 4000, dtype=np.float32)
     clouds["line"] = line
+    # clouds far from the origin.  The per-cell lower bounds of the one-wave-per-query kernel must be taken
+    # in the frame of the cell assignment ((x - min) * 1/h), or their rounding grows with |min| - at 1 km one ulp of
+    # `min + cell * h` is 6e-5 m, as much as the bound's safety margin - and a cell holding one of the 51 neighbours is
+    # skipped.  The spikes cloud (the queries that reach that kernel) 1 km and 8 km out, on both axes.
+    for name, (ox, oy) in (("spikes 1 km out", (1000.0, -1000.0)), ("spikes 8 km out", (-8000.0, 8000.0))):
+        far = spikes.copy()
+        far["x"] += np.float32(ox)
+        far["y"] += np.float32(oy)
+        clouds[name] = far
     disp, bgr = frame_1248
     _, row = __import__("test_cli_pose").pose_row_for_image(1248)
     clouds["frame 1248"] = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=1),
