@@ -75,6 +75,7 @@ struct o3dr_ctx {
     int slab_shift_env = -2;  // O3DR_SLABS=0: plain pixel order in the fused batch path; O3DR_SLABS=sN: slabs of 2^N cells; else automatic
     int exact_box = 0;       // O3DR_EXACT_BOX=1: the batch path always takes the exact bounding box (k_reproject_bbox_count)
     int use_runs = 1;        // O3DR_RUNS=0: whole-cloud voxel grids sort points instead of runs; 2: always runs
+    int small_path = 1;      // O3DR_SMALL=0: clouds of at most kSmallMax points take the general path too
 
     Workspace ws;
     size_t ws_elems = 0;   // frames*(cap+1) the per-point arrays were allocated for
@@ -107,6 +108,9 @@ struct o3dr_ctx {
     CloudCounters* cc_big = nullptr;   // device
     CloudCounters* cc_tmp = nullptr;   // device, for single-shot calls
     CloudCounters* cc_host = nullptr;  // pinned
+    CloudCounters* cc_host_dev = nullptr;  // ... as the device sees it: a one-workgroup call (kernels/small.inc) writes its result's
+                                           // size straight into it, and the host reads it after the one synchronisation
+    uint8_t* small_host = nullptr;     // pinned staging for the outputs of those calls (kSmallMax points)
     uint32_t* n_host = nullptr;        // pinned scratch (4 words)
     uint8_t* misc_dev = nullptr;       // 4 KiB device scratch: bbox (6 f32) | overflow (u32) | part counts (256 u64)
     uint8_t* misc_host = nullptr;      // pinned mirror
@@ -353,6 +357,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
         hipMalloc((void**)&c->cc_tmp, sizeof(CloudCounters)) != hipSuccess ||
         hipHostMalloc((void**)&c->cc_host, 2 * sizeof(CloudCounters), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->n_host, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->small_host, (size_t)kSmallMax * sizeof(o3dr_point), hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->cc_host_dev, c->cc_host, 0) != hipSuccess ||
         hipMalloc((void**)&c->stats_dev, sizeof(SortStats)) != hipSuccess ||
         hipMalloc((void**)&c->misc_dev, 4096) != hipSuccess ||
         hipHostMalloc((void**)&c->misc_host, 4096, hipHostMallocDefault) != hipSuccess ||
@@ -375,6 +381,8 @@ extern "C" int o3dr_ctx_create(int device_id, o3dr_ctx** out_ctx)
     if (getenv("O3DR_NO_CLOUD_BOX")) c->cloud_box_enable = 0;
     const char* eb_env = getenv("O3DR_EXACT_BOX");
     c->exact_box = eb_env && atoi(eb_env) == 1;
+    const char* sm_env = getenv("O3DR_SMALL");
+    if (sm_env) c->small_path = atoi(sm_env) != 0;
     const char* th_env = getenv("O3DR_TEST_HOOKS");
     c->test_hooks = th_env && atoi(th_env) == 1;
     const char* sl_env = getenv("O3DR_SLABS");
@@ -418,6 +426,7 @@ extern "C" int o3dr_ctx_destroy(o3dr_ctx* c)
     if (c->cc_tmp) (void)hipFree(c->cc_tmp);
     if (c->cc_host) (void)hipHostFree(c->cc_host);
     if (c->n_host) (void)hipHostFree(c->n_host);
+    if (c->small_host) (void)hipHostFree(c->small_host);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
     if (c->misc_dev) (void)hipFree(c->misc_dev);
     if (c->misc_host) (void)hipHostFree(c->misc_host);
@@ -778,7 +787,50 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
     }
     int64_t n_final = 0;
     uint32_t st = 0;
-    if (!downsample) {
+    // Frames of at most kSmallMax candidates - the reference's own configuration, --jump_pixels 10 .. 15 - take the whole
+    // path in ONE launch of one workgroup (kernels/small.inc) instead of ~45 launches that cost their latency and nothing
+    // else; with the outlier removal on, its kernels run between the two halves.  O3DR_SMALL=0 switches it off.
+    const bool small = c->small_path && cap <= kSmallMax && !c->params.disparity_f64 && !c->test_corrupt;
+    if (small) {
+        const uint8_t* dsp = (const uint8_t*)disp_d;
+        int64_t dsp_pitch = disp_pitch, dsp_fstride = 0;
+        CHK(maybe_blur(c, &dsp, &dsp_pitch, &dsp_fstride, rows, cols, 1));
+        ReprojectArgs a;
+        fill_args(c, a, dsp, dsp_pitch, 0, (const uint8_t*)bgr_d, bgr_pitch, 0, rows, cols, g, 0);
+        if (T) {
+            a.xf_mode = 1;
+            for (int i = 0; i < 12; ++i) a.T[i] = T[i];
+        }
+        float leaf[3];
+        leaf[0] = leaf[1] = leaf[2] = (float)(c->params.voxel_size / 5);  // pose_functions.cpp:1698
+        const bool with_sor = downsample && sor_on(c);
+        // the result's size lands in pinned host memory, written by the kernel itself; host outputs come back in the same
+        // wait (all `cap` slots, at most 128 KiB, through a pinned staging buffer): ONE synchronisation per call
+        if (with_sor) {
+            CHK(sor_ensure(c, 1, cap));
+            launch_small_frame(&c->prof, c->stream, a, (const float*)kp_d, n_kp, 0, leaf, nullptr, c->ws.pts, c->cc_tmp, c->ws.n_valid, c->ws.mm);
+            (void)launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, 0, c->ws.n_valid, 1, cap, 1, 1.0, c->ws.sor_pts, 0, c->ws.sor_n);
+            launch_small_voxel(&c->prof, c->stream, c->ws.sor_pts, c->ws.sor_n, 0, nullptr, leaf, 0, 0.f, final_dst, c->cc_host_dev);
+        } else {
+            launch_small_frame(&c->prof, c->stream, a, (const float*)kp_d, n_kp, downsample ? 1 : 0, leaf, c->ws.pts, final_dst, c->cc_host_dev,
+                               nullptr, nullptr);
+        }
+        HIPCHK(hipGetLastError());
+        if (mem == O3DR_MEM_HOST)
+            HIPCHK(hipMemcpyAsync(c->small_host, final_dst, (size_t)cap * sizeof(o3dr_point), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const CloudCounters cc = *c->cc_host;
+        if (cc.status & O3DR_STATUS_INTERNAL)
+            return fail(O3DR_ERR_INTERNAL, "a device-side gather guard tripped (record or point id outside its cloud); results are invalid");
+        if ((int64_t)cc.count > cap) return fail(O3DR_ERR_INTERNAL, "the one-workgroup path returned more points than it was given");
+        if (mem == O3DR_MEM_HOST) {
+            if ((int64_t)cc.count > out_capacity) return fail(O3DR_ERR_CAPACITY, "output buffer too small");
+            memcpy(out, c->small_host, (size_t)cc.count * sizeof(o3dr_point));
+        }
+        *n_out = (int64_t)cc.count;
+        if (status) *status = cc.status;
+        return O3DR_OK;
+    } else if (!downsample) {
         CHK(run_reproject_single(c, (const uint8_t*)disp_d, disp_pitch, (const uint8_t*)bgr_d, bgr_pitch, rows, cols, g,
                                  T, (const float*)kp_d, n_kp, final_dst));
         uint32_t nv = 0;
@@ -901,6 +953,23 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
                         const float* box_dev = nullptr, const uint8_t* heads_in = nullptr, CloudCounters* big_out = nullptr)
 {
     CHK(ws_ensure(c, 1, n_in, false, c->use_runs != 0));
+    if (c->small_path && n_in <= kSmallMax && !do_sor && !c->test_corrupt) {  // one launch of one workgroup (kernels/small.inc)
+        const float* box = box_dev;
+        if (gmin && gmax) {
+            CHK(put_bbox(c, gmin, gmax));
+            box = c->ws.mm;
+        }
+        launch_small_voxel(&c->prof, c->stream, in_d, nullptr, (uint32_t)n_in, box, leaf, min_points, z_offset, out_d, c->cc_tmp);
+        HIPCHK(hipGetLastError());
+        CloudCounters cc;
+        if (big_out)
+            CHK(read_counters(c, c->cc_tmp, &cc, c->cc_big, big_out));
+        else
+            CHK(read_counters(c, c->cc_tmp, &cc));
+        *n_out = (int64_t)cc.count;
+        if (status) *status = cc.status;
+        return O3DR_OK;
+    }
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
     int mm_used = 1;
     if (gmin && gmax)  // grid laid over a caller-supplied (global) box instead of this cloud's own

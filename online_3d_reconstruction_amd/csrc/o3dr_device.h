@@ -38,6 +38,7 @@ constexpr int kXcds = 8;   // accelerator complex dies of an MI355X, each with i
 constexpr int kPtThreads = 256;
 constexpr int kSegTile = 1024;  // sorted keys per workgroup in the run-head kernels
 constexpr int kMinmaxBlocks = 1024;  // workgroups (= bounding-box slots) of the stand-alone min/max pass
+constexpr int kSmallMax = 8192;      // points one workgroup takes through the whole path in one launch (kernels/small.inc)
 // whole-cloud voxel grids (the merge): records of the sort are runs of consecutive points inside one GROUP of
 // 2^kGroupBits consecutive voxel indices; one wave then sums a group, lane = voxel (k_centroid_groups)
 constexpr int kGroupBits = 5;
@@ -228,6 +229,18 @@ struct VoxelArgs {
 constexpr int kBoxFoldBlocks = 1024;  // workgroups (and partial boxes) of the running-bounding-box fold
 void launch_voxel_grid(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v);
 void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t value, int frames);
+// Small clouds (at most kSmallMax points) in ONE launch of ONE workgroup (kernels/small.inc).
+//  launch_small_frame: A1 (+ A2 by a.xf_mode) of one frame, keypoints first; downsample != 0: followed by the voxel grid
+//    with `leaf` (pts: scratch for kSmallMax points); out / cc receive the result and its size; n_out_dev / box_out6
+//    (optional): the size as a plain word and the bounding box of the points, for launch_sor.
+//  launch_small_voxel: the voxel grid of a cloud that already exists (n_in_dev == nullptr: n_in points), over its own
+//    bounding box or over box6 (device).
+void launch_small_frame(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp, int downsample,
+                        const float leaf[3], o3dr_point* pts, o3dr_point* out, CloudCounters* cc, uint32_t* n_out_dev,
+                        float* box_out6);
+void launch_small_voxel(Profiler* pf, hipStream_t s, const o3dr_point* in, const uint32_t* n_in_dev, uint32_t n_in,
+                        const float* box6, const float leaf[3], uint32_t min_points, float z_offset, o3dr_point* out,
+                        CloudCounters* cc);
 // cv::bilateralFilter on u8 images; tab = color_weight[256] | space_weight[maxk] | tile offsets [maxk] (device)
 constexpr int kBilMaxRadius = 64;
 void launch_bilateral(Profiler* pf, hipStream_t s, const uint8_t* src, int64_t src_pitch, int64_t src_fstride, int rows,

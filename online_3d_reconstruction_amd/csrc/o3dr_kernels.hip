@@ -24,7 +24,10 @@
 //   voxel_runs   run heads/starts, min_points filter, centroid kernels, run-compressed variants, running bbox
 //   multigpu     bounding-box fold, index-slice partition
 //   sor          statistical outlier removal
+//   small        clouds of at most kSmallMax points: the whole path in one launch of one workgroup
 // The launchers follow in this file.
+#include <string.h>
+
 #include "o3dr_device.h"
 #include "o3dr_profile.h"
 
@@ -39,6 +42,7 @@ namespace o3dr {
 #include "kernels/voxel_runs.inc"
 #include "kernels/multigpu.inc"
 #include "kernels/sor.inc"
+#include "kernels/small.inc"
 
 // =================================================================================================
 // launchers
@@ -71,6 +75,48 @@ void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t va
 {
     ProfScope ps(pf, O3DR_K_OTHER, s);
     k_set_counts<<<cdiv64(frames, 256), 256, 0, s>>>(n_dev, value, frames);
+}
+
+void launch_small_frame(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp, int downsample,
+                        const float leaf[3], o3dr_point* pts, o3dr_point* out, CloudCounters* cc, uint32_t* n_out_dev,
+                        float* box_out6)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    SmallArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.reproject = 1;
+    sa.kp_xy = kp_xy;
+    sa.n_kp = n_kp;
+    sa.downsample = downsample;
+    for (int i = 0; i < 3; ++i) sa.leaf[i] = leaf[i];
+    sa.pts = pts;
+    sa.out = out;
+    sa.cc = cc;
+    sa.n_out_dev = n_out_dev;
+    sa.box_out6 = box_out6;
+    k_small<<<1, kSmallThreads, 0, s>>>(a, sa);
+}
+
+void launch_small_voxel(Profiler* pf, hipStream_t s, const o3dr_point* in, const uint32_t* n_in_dev, uint32_t n_in,
+                        const float* box6, const float leaf[3], uint32_t min_points, float z_offset, o3dr_point* out,
+                        CloudCounters* cc)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    ReprojectArgs a;
+    memset(&a, 0, sizeof a);
+    SmallArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.downsample = 1;
+    sa.in = in;
+    sa.n_in_dev = n_in_dev;
+    sa.n_in = n_in;
+    sa.box6 = box6;
+    for (int i = 0; i < 3; ++i) sa.leaf[i] = leaf[i];
+    sa.min_points = min_points;
+    sa.z_offset = z_offset;
+    sa.out = out;
+    sa.cc = cc;
+    k_small<<<1, kSmallThreads, 0, s>>>(a, sa);
 }
 
 void launch_keypoint_pass(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp,

@@ -38,6 +38,16 @@ def timed(name, fn, reps=100):
 
 timed("create_and_transform_device_us", lambda: ctx.createAndTransformPtCloud(disp[0], bgr[0], poses_h[0]))
 timed("create_and_transform_host_us", lambda: ctx.createAndTransformPtCloud(disp_h[0], bgr_h[0], poses_h[0]))
+# the reference's own frame sizes: --jump_pixels 15 (3 404 candidates) and 10 (7 480): one launch of one workgroup
+# (kernels/small.inc) unless O3DR_SMALL=0
+for jump in (15, 10):
+    ctx.set_params(o3dr.Params(jump_pixels=jump, voxel_size=0.05, sor_enable=SOR))
+    timed(f"create_and_transform_jump{jump}_device_us", lambda: ctx.createAndTransformPtCloud(disp[0], bgr[0], poses_h[0]), 300)
+    timed(f"create_and_transform_jump{jump}_host_us", lambda: ctx.createAndTransformPtCloud(disp_h[0], bgr_h[0], poses_h[0]), 300)
+small_cloud = ctx.createAndTransformPtCloud(disp_h[0], bgr_h[0], poses_h[0])
+timed("downsample_combined_small_cloud_host_us", lambda: ctx.downsamplePtCloud(small_cloud, True), 300)
+ctx.set_params(o3dr.Params(jump_pixels=1, voxel_size=0.05, sor_enable=SOR))
+out["small_path"] = os.environ.get("O3DR_SMALL", "1") != "0"
 ctx.cloudBigReserve(32 * ctx.max_points(rows, cols))
 for nf in (1, 7, 32):
     def step(nf=nf):

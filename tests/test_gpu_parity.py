@@ -229,6 +229,105 @@ def test_A6_create_and_transform_pt_cloud(ctx, orc, Q, frame_1248, frame_1249, j
         assert_points_equal(got, ref, f"A6 jump={jump} vs={vs} frame {k}")
 
 
+def test_small_clouds_one_launch_path_equals_the_general_path_and_the_oracle(orc, Q, frame_1248, frame_1249, frame_B, monkeypatch):
+    """Frames and clouds of at most 8192 points take the whole path in ONE launch of one workgroup (kernels/small.inc:
+    the reference's own --jump_pixels 10 .. 15 frames are 3 404 .. 7 480 candidates).  Same inputs through a context with
+    that path (default) and one without it (O3DR_SMALL=0: the general ~45-launch path), and through the oracle: A1, A1 + A2,
+    A6 with keypoints, dont_downsample, the outlier removal on, blur, all-invalid and one-point frames, the per-frame and
+    the combined voxel grid with min_points_per_voxel, a caller-given leaf, PCL's overflow fallback in both modes, and
+    sizes around the limit (8191, 8192 take it; 8193 does not)."""
+    import online_3d_reconstruction_amd as o3dr
+    fast = o3dr.Context(0, Q=Q)
+    monkeypatch.setenv("O3DR_SMALL", "0")
+    slow = o3dr.Context(0, Q=Q)
+    monkeypatch.delenv("O3DR_SMALL")
+    rng = np.random.default_rng(5)
+    try:
+        for jump in (15, 10, 9):
+            for k, (disp, bgr) in enumerate((frame_1248, frame_1249, frame_B)):
+                T = _pose(30 + k)
+                kp = np.stack([rng.uniform(100, 1270, 300), rng.uniform(0, 719, 300)], 1).astype(np.float32)
+                for sor in (False, True):
+                    prm = _params(jump_pixels=jump, voxel_size=0.05, sor_enable=sor)
+                    fast.set_params(prm)
+                    slow.set_params(prm)
+                    a, sa = fast.createAndTransformPtCloud(disp, bgr, T, kp_xy=kp, return_status=True)
+                    b, sb = slow.createAndTransformPtCloud(disp, bgr, T, kp_xy=kp, return_status=True)
+                    if sor:  # A1 -> A2 -> outlier removal -> per-frame grid (pose_functions.cpp:1673-1700)
+                        world = orc.transform_pt_cloud(orc.create_single_img_pt_cloud(disp, bgr, Q, jump_pixels=jump, kp_xy=kp), T)
+                        ref, rst = orc.downsample_pt_cloud(orc.statistical_outlier_removal(world)[0], 0.05, False, 1)
+                    else:
+                        ref, rst = orc.create_and_transform_pt_cloud(disp, bgr, Q, T, 0.05, jump_pixels=jump, kp_xy=kp)
+                    assert sa == sb == rst
+                    assert_points_equal(a, b, f"A6 small vs general path, jump {jump} frame {k} sor {sor}")
+                    assert_points_equal(a, ref, f"A6 small path vs oracle, jump {jump} frame {k} sor {sor}")
+                assert_points_equal(fast.createSingleImgPtCloud(disp, bgr, kp_xy=kp), slow.createSingleImgPtCloud(disp, bgr, kp_xy=kp), "A1")
+                assert_points_equal(fast.reprojectTransform(disp, bgr, T, kp_xy=kp), slow.reprojectTransform(disp, bgr, T, kp_xy=kp), "A1+A2")
+        disp, bgr = frame_1248
+        for prm in (_params(jump_pixels=15, voxel_size=0.05, dont_downsample=True), _params(jump_pixels=15, voxel_size=0.05, blur_kernel=7),
+                    _params(jump_pixels=15, voxel_size=1e-4)):  # (the last one: the per-frame grid trips PCL's overflow guard)
+            fast.set_params(prm)
+            slow.set_params(prm)
+            a, sa = fast.createAndTransformPtCloud(disp, bgr, _pose(1), return_status=True)
+            b, sb = slow.createAndTransformPtCloud(disp, bgr, _pose(1), return_status=True)
+            assert sa == sb and len(a) > 0
+            assert_points_equal(a, b, f"A6 small vs general path, {prm}")
+        ref, rst = orc.create_and_transform_pt_cloud(disp, bgr, Q, _pose(1), 1e-4, jump_pixels=15)
+        assert rst == orc.STATUS_VOXEL_OVERFLOW == sa
+        assert_points_equal(a, ref, "A6 small path, overflow fallback vs oracle")
+        empty = np.zeros_like(disp)
+        one = empty.copy()
+        one[20 + 15 * 7, 160 + 15 * 11] = 100
+        prm = _params(jump_pixels=15, voxel_size=0.05)
+        fast.set_params(prm)
+        slow.set_params(prm)
+        assert len(fast.createAndTransformPtCloud(empty, bgr, _pose(1))) == 0
+        assert_points_equal(fast.createAndTransformPtCloud(one, bgr, _pose(1)), slow.createAndTransformPtCloud(one, bgr, _pose(1)), "one point")
+        assert len(fast.createAndTransformPtCloud(one, bgr, _pose(1))) == 1
+        # whole-cloud calls on small clouds
+        for n in (1, 2, 63, 64, 65, 1000, 4097, 8191, 8192, 8193):
+            pts = random_cloud(n, 900 + n, extent=(1.2, 0.9, 0.4))
+            for vs, minpts in ((0.05, 1), (0.2, 3)):
+                prm = _params(voxel_size=vs, min_points_per_voxel=minpts)
+                fast.set_params(prm)
+                slow.set_params(prm)
+                for combined in (False, True):
+                    a, sa = fast.downsamplePtCloud(pts, combined, return_status=True)
+                    b, sb = slow.downsamplePtCloud(pts, combined, return_status=True)
+                    ref, rst = orc.downsample_pt_cloud(pts, vs, combined, minpts)
+                    assert sa == sb == rst
+                    assert_points_equal(a, b, f"downsamplePtCloud small vs general path, n {n} vs {vs} combined {combined}")
+                    assert_points_equal(a, ref, f"downsamplePtCloud small path vs oracle, n {n} vs {vs} combined {combined}")
+            leaf = np.array([0.05, 0.07, 0.11], np.float32)
+            a, sa = fast.voxelGrid(pts, leaf, 2, return_status=True)
+            ref, rst = orc.voxel_grid(pts, leaf, 2)
+            assert sa == rst
+            assert_points_equal(a, ref, f"voxelGrid small path vs oracle, n {n}")
+        # many records in one bucket of the one-workgroup path's bucket sort (a clump inside a few voxels next to a spread-out
+        # remainder): the bitonic network takes over, for the packed (<= 4096) and the split record layout
+        for n in (3000, 8000):
+            clump = np.concatenate([random_cloud(n - 500, 40 + n, extent=(0.03, 0.03, 0.03)), random_cloud(500, 41 + n, extent=(2.0, 2.0, 0.5))])
+            clump = clump[np.random.default_rng(n).permutation(len(clump))]
+            for vs, combined in ((0.05, False), (0.05, True), (1.0, False)):
+                prm = _params(voxel_size=vs)
+                fast.set_params(prm)
+                slow.set_params(prm)
+                a = fast.downsamplePtCloud(clump, combined)
+                ref, _ = orc.downsample_pt_cloud(clump, vs, combined, 1)
+                assert_points_equal(a, slow.downsamplePtCloud(clump, combined), f"clump {n} vs {vs} combined {combined}: small vs general path")
+                assert_points_equal(a, ref, f"clump {n} vs {vs} combined {combined}: small path vs oracle")
+        wide = random_cloud(5000, 6, extent=(3000.0, 3000.0, 1.0))  # PCL's overflow guard: output = input (+- 500 round trip)
+        fast.set_params(_params(voxel_size=0.05))
+        for combined in (False, True):
+            a, sa = fast.downsamplePtCloud(wide, combined, return_status=True)
+            ref, rst = orc.downsample_pt_cloud(wide, 0.05, combined, 1)
+            assert sa == rst == orc.STATUS_VOXEL_OVERFLOW
+            assert_points_equal(a, ref, f"small path, overflow fallback, combined {combined}")
+    finally:
+        fast.close()
+        slow.close()
+
+
 def test_A6_dont_downsample(ctx, orc, Q, frame_1249):
     disp, bgr = frame_1249
     T = _pose(9)
