@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; what a plain device copy reaches on the box is measured below
                        # (roofline.measured_copy_GBps: 4.7-5.6 TB/s read+write over the boxes seen so far)
 
