@@ -148,7 +148,7 @@ def _assert_ply_equals(got, ref):
 @pytest.mark.parametrize("extra", [[], ["--reference_fanout"], ["--blur_kernel", "30", "--sor", "0"],
                                    ["--blur_kernel", "5", "--reference_fanout", "--sor", "0"], ["--sor", "0"],
                                    ["--sor", "1", "--blur_kernel", "5", "--reference_fanout"]])
-def test_cli_runs_config1_frames_and_matches_oracle(tmp_path, orc, Q, extra):
+def test_cli_runs_configs0_frames_and_matches_oracle(tmp_path, orc, Q, extra):
     from online_3d_reconstruction_amd import synth
     assert os.path.exists(POSE_BIN), "run `make` / __graft_entry__.build() first"
     tmp = str(tmp_path)
@@ -172,8 +172,8 @@ def test_cli_runs_config1_frames_and_matches_oracle(tmp_path, orc, Q, extra):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--reference_fanout", "--seq_len", "3"], ["--partitioned_merge", "--seq_len", "2"]])
-def test_cli_config1_all_seven_bundled_frames(tmp_path, orc, Q, extra):
-    """BASELINE config 1 on every frame of 1230-1280 the reference bundles: 1239 and 1240 are rejected
+def test_cli_configs0_all_seven_bundled_frames(tmp_path, orc, Q, extra):
+    """BASELINE.json configs[0] on every frame of 1230-1280 the reference bundles: 1239 and 1240 are rejected
     by the variance gate (pose.cpp:187-196), 1246, 1248, 1249, 1251, 1255 accepted, all other numbers unreadable
     (pose.cpp:164-177); the reference's literal command line (outlier removal on), cloud.ply equal to the oracle's.
     --partitioned_merge: the C++ multi-GPU path (o3dr_merge_partitioned over an RCCL communicator, here of one rank:

@@ -408,8 +408,8 @@ def test_A7_batches_device_resident_and_incremental(ctx, orc):
     assert_points_equal(ctx.cloudBigRead(), orc.transform_pt_cloud(rbig, T), "cloud_big re-transform")
 
 
-def test_config4_overflow_frames_pass_through(ctx, orc):
-    """BASELINE config 4 shape in miniature: voxel_size 0.02 -> per-frame leaf 0.004 m makes PCL's
+def test_configs3_overflow_frames_pass_through(ctx, orc):
+    """BASELINE.json configs[3]'s shape in miniature: voxel_size 0.02 -> per-frame leaf 0.004 m makes PCL's
     index overflow guard fire, so per-frame clouds pass through and the merge sees raw points."""
     from online_3d_reconstruction_amd import synth
     Qs = synth.camera_Q(1080, 1920)
@@ -423,7 +423,7 @@ def test_config4_overflow_frames_pass_through(ctx, orc):
     small, fst = ctx.finalize(return_status=True)
     rbig, rsmall, _ = _oracle_run(orc, Qs, disp, bgr, poses, 0.02, 1, 3)
     assert st == orc.STATUS_VOXEL_OVERFLOW and n == len(rbig) == 2 * 1040 * 1660
-    assert_points_equal(small, rsmall, "config 4 cloud_small")
+    assert_points_equal(small, rsmall, "configs[3] cloud_small")
     ctx.set_camera(synth.camera_Q())
 
 
@@ -463,8 +463,8 @@ def test_conservative_box_at_the_edge_of_pcls_overflow_guard(orc, monkeypatch):
     assert sides == {0, orc.STATUS_VOXEL_OVERFLOW}  # the sweep saw frames on both sides of the guard
 
 
-# ---- BASELINE's full dense size (configs[1]): 200 frames, against the oracle and through size-independent properties --
-def test_full_size_config1_200_frames(ctx, orc):
+# ---- BASELINE.json configs[1] at its full size: 200 dense frames, against the oracle and through size-independent properties --
+def test_full_size_configs1_200_dense_frames_against_the_oracle(ctx, orc):
     """the headline workload itself: 200 dense 720p frames -> cloud_big (98 M points) -> merged cloud, bit for bit
     against orc.run_frames; plus what the domain guarantees (sortedness by voxel index, one point per XY cell,
     idempotent occupancy, bounding box)."""
@@ -495,6 +495,64 @@ def test_full_size_config1_200_frames(ctx, orc):
     assert small["x"].min() >= big["x"].min() and small["x"].max() <= big["x"].max()
     assert np.abs(small["z"]).max() < 30
     ctx.cloudBigReset()
+
+
+def test_full_size_configs2_2000_dense_frames_through_size_independent_properties(Q):
+    """BASELINE.json configs[2]'s workload on ONE GPU: 2000 dense 720p frames -> cloud_big of 982 M points (15.7 GB, more
+    than 2^29 records through 64-bit offsets, several reallocations of the cloud) -> one merge of all of them into 4.3 M
+    cells.  The oracle takes minutes at this size (bench.py --total-frames 2000 runs it: profiles/
+    r04_configs2_2000frames_1gpu.json, verified), so this test uses what the domain guarantees at any size:
+      * frames are independent: the first 200 frames' part of cloud_big is, bit for bit, the cloud_big of a 200-frame run
+        (which test_full_size_configs1_... holds against the oracle), and cloud_big's size is the sum of the chunks';
+      * the merged cloud is strictly ascending in PCL's index order, one point per XY cell, every z on the 2^-15 m grid of
+        the fp32 +500 round trip;
+      * occupancy is a union: the full merge's cells are exactly the union of the cells of the ten 200-frame chunks' merges;
+      * the merge is a fixed point of its own occupancy and colours."""
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    from online_3d_reconstruction_amd.api import points_from_torch
+    Qs = synth.camera_Q()
+    prm = _params(jump_pixels=1, voxel_size=0.05)
+    F, C = 2000, 200
+    vs = np.float32(0.05)
+
+    def cells(c):
+        return np.floor(c["y"] / vs).astype(np.int64) * (1 << 32) + (np.floor(c["x"] / vs).astype(np.int64) & 0xffffffff)
+
+    full = o3dr.Context(0, Q=Qs, params=prm)
+    part = o3dr.Context(0, Q=Qs, params=prm)
+    try:
+        sizes, union, first_big = [], [], None
+        for a in range(0, F, C):
+            disp, bgr = synth.make_frames(a, C)
+            poses = synth.make_poses(a, C)
+            full.accumulateFrames(disp, bgr, poses)
+            part.cloudBigReset()
+            part.accumulateFrames(disp, bgr, poses)
+            n, st = part.cloudBigSize()
+            assert st == 0
+            sizes.append(n)
+            if a == 0:
+                first_big = part.cloudBigRead()
+            union.append(cells(part.finalize()))
+            del disp, bgr
+        n_all, st = full.cloudBigSize()
+        assert st == 0 and n_all == sum(sizes) and n_all > (1 << 29)
+        view = full.cloudBigView()  # [n, 4] int32 in HBM
+        assert view.shape[0] == n_all
+        assert_points_equal(points_from_torch(view[: sizes[0]]), first_big, "first 200 frames' part of the 2000-frame cloud_big")
+        del view, first_big
+        small = full.finalize()
+        lin = cells(small)
+        assert np.all(np.diff(lin) > 0)
+        assert np.array_equal(lin, np.unique(np.concatenate(union)))
+        q = small["z"].astype(np.float64) * 2.0 ** 15
+        assert np.array_equal(q, np.rint(q))
+        again = part.downsamplePtCloud(small, True)
+        assert len(again) == len(small) and np.array_equal(again["rgba"], small["rgba"])
+    finally:
+        full.close()
+        part.close()
 
 
 # ---- multi-GPU merge pieces on one GPU: virtual ranks, exchange done by hand ---------------------------
@@ -689,14 +747,14 @@ def test_merge_partitioned_failure_on_one_rank_is_collective(Q, point, gather, m
         assert_points_equal(np.concatenate(got), ref, f"second exchange (slices) after an injected failure at step {point}")
 
 
-@pytest.mark.parametrize("shape", ["config3_dense_720p", "config5_4k_jump4"])
+@pytest.mark.parametrize("shape", ["configs2_dense_720p", "configs4_4k_jump4"])
 def test_partitioned_merge_world8_config_shapes(orc, shape):
     """BASELINE configs[2] and configs[4] shapes through the 8-rank partitioned merge (8 virtual ranks on one GPU, two
     frames each): dense (jump 1) 1280x720 frames, and 4096x2160 frames at jump_pixels 4; against the single-context
     merge AND the oracle's run over all frames."""
     from online_3d_reconstruction_amd import synth
     world, F = 8, 16
-    if shape == "config3_dense_720p":
+    if shape == "configs2_dense_720p":
         rows, cols, jump = 720, 1280, 1
     else:
         rows, cols, jump = 2160, 4096, 4
@@ -710,8 +768,8 @@ def test_partitioned_merge_world8_config_shapes(orc, shape):
     assert_points_equal(got, rsmall, f"{shape}: partitioned merge vs the oracle")
 
 
-def test_config5_shape_batched_accumulate_and_finalize(ctx, orc):
-    """BASELINE config 5 shape through the BATCHED path: 4 frames of 4096x2160 at jump_pixels 4 (strided rows, generic
+def test_configs4_shape_batched_accumulate_and_finalize(ctx, orc):
+    """BASELINE.json configs[4]'s shape through the BATCHED path: 4 frames of 4096x2160 at jump_pixels 4 (strided rows, generic
     load path, 472 230 candidates per frame) -> accumulateFrames -> finalize, host and device inputs"""
     import torch
     from online_3d_reconstruction_amd import synth
@@ -731,15 +789,15 @@ def test_config5_shape_batched_accumulate_and_finalize(ctx, orc):
                 ctx.accumulateFrames(disp, bgr, poses)
             n, st = ctx.cloudBigSize()
             assert st == 0
-            assert_points_equal(ctx.cloudBigRead(), rbig, f"config 5 cloud_big (device inputs: {device})")
-            assert_points_equal(ctx.finalize(), rsmall, f"config 5 merged cloud (device inputs: {device})")
+            assert_points_equal(ctx.cloudBigRead(), rbig, f"configs[4] cloud_big (device inputs: {device})")
+            assert_points_equal(ctx.finalize(), rsmall, f"configs[4] merged cloud (device inputs: {device})")
     finally:
         ctx.set_camera(synth.camera_Q())
         ctx.cloudBigReset()
 
 
-def test_config5_shape_4k_semidense(ctx, orc):
-    """BASELINE config 5 shape: 4096x2160, jump_pixels 4 (strided rows, generic load path), one frame"""
+def test_configs4_shape_4k_semidense(ctx, orc):
+    """BASELINE.json configs[4]'s shape: 4096x2160, jump_pixels 4 (strided rows, generic load path), one frame"""
     from online_3d_reconstruction_amd import synth
     Qs = synth.camera_Q(2160, 4096)
     ctx.set_camera(Qs)
@@ -750,7 +808,7 @@ def test_config5_shape_4k_semidense(ctx, orc):
     got, st = ctx.createAndTransformPtCloud(disp, bgr, T, return_status=True)
     ref, rst = orc.create_and_transform_pt_cloud(disp, bgr, Qs, T, 0.05, jump_pixels=4)
     assert st == rst
-    assert_points_equal(got, ref, "config 5 frame")
+    assert_points_equal(got, ref, "configs[4] frame")
     ctx.set_camera(synth.camera_Q())
 
 

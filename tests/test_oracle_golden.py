@@ -411,7 +411,7 @@ def test_disparity_variance_equals_the_reference_runs_own_log(orc):
         assert f"{got:.6g}" == logged, (name, got, logged)
 
 
-def test_variance_gate_on_the_seven_bundled_frames_of_config1(orc):
+def test_variance_gate_on_the_seven_bundled_frames_of_configs0(orc):
     """pose.cpp:187-196 rejects a frame iff disp_img_var > 5: of the seven frames bundled in 1230-1280, 1239 and
     1240 are rejected (27.2 and 18.7, large invalid regions), the other five accepted"""
     from conftest import load_frame
