@@ -809,7 +809,7 @@ static int frame_call(o3dr_ctx* c, const uint8_t* disp, int64_t disp_pitch, cons
         if (with_sor) {
             CHK(sor_ensure(c, 1, cap));
             launch_small_frame(&c->prof, c->stream, a, (const float*)kp_d, n_kp, 0, leaf, nullptr, c->ws.pts, c->cc_tmp, c->ws.n_valid, c->ws.mm);
-            (void)launch_sor(&c->prof, c->stream, c->ws, c->ws.pts, 0, c->ws.n_valid, 1, cap, 1, 1.0, c->ws.sor_pts, 0, c->ws.sor_n);
+            launch_sor_small(&c->prof, c->stream, c->ws, c->ws.pts, c->ws.n_valid, cap, 1.0, c->ws.sor_pts, c->ws.sor_n);
             launch_small_voxel(&c->prof, c->stream, c->ws.sor_pts, c->ws.sor_n, 0, nullptr, leaf, 0, 0.f, final_dst, c->cc_host_dev);
         } else {
             launch_small_frame(&c->prof, c->stream, a, (const float*)kp_d, n_kp, downsample ? 1 : 0, leaf, c->ws.pts, final_dst, c->cc_host_dev,
@@ -953,13 +953,20 @@ static int voxel_single(o3dr_ctx* c, const o3dr_point* in_d, int64_t n_in, const
                         const float* box_dev = nullptr, const uint8_t* heads_in = nullptr, CloudCounters* big_out = nullptr)
 {
     CHK(ws_ensure(c, 1, n_in, false, c->use_runs != 0));
-    if (c->small_path && n_in <= kSmallMax && !do_sor && !c->test_corrupt) {  // one launch of one workgroup (kernels/small.inc)
+    if (c->small_path && n_in <= kSmallMax && !c->test_corrupt) {  // one launch of one workgroup (kernels/small.inc)
         const float* box = box_dev;
         if (gmin && gmax) {
             CHK(put_bbox(c, gmin, gmax));
             box = c->ws.mm;
         }
-        launch_small_voxel(&c->prof, c->stream, in_d, nullptr, (uint32_t)n_in, box, leaf, min_points, z_offset, out_d, c->cc_tmp);
+        if (do_sor) {  // ... after the outlier removal's five
+            CHK(sor_ensure(c, 1, n_in));
+            launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
+            launch_sor_small(&c->prof, c->stream, c->ws, in_d, c->ws.n_valid, n_in, 1.0, c->ws.sor_pts, c->ws.sor_n);
+            launch_small_voxel(&c->prof, c->stream, c->ws.sor_pts, c->ws.sor_n, 0, box, leaf, min_points, z_offset, out_d, c->cc_tmp);
+        } else {
+            launch_small_voxel(&c->prof, c->stream, in_d, nullptr, (uint32_t)n_in, box, leaf, min_points, z_offset, out_d, c->cc_tmp);
+        }
         HIPCHK(hipGetLastError());
         CloudCounters cc;
         if (big_out)
@@ -1076,9 +1083,13 @@ extern "C" int o3dr_statistical_outlier_removal(o3dr_ctx* c, const o3dr_point* i
     CHK(ws_ensure(c, 1, n_in, false));
     CHK(sor_ensure(c, 1, n_in));
     launch_set_counts(&c->prof, c->stream, c->ws.n_valid, (uint32_t)n_in, 1);
-    const int used = launch_points_minmax(&c->prof, c->stream, (const o3dr_point*)in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
     o3dr_point* dst = mem == O3DR_MEM_DEVICE ? out : c->ws.sor_pts;
-    launch_sor(&c->prof, c->stream, c->ws, (const o3dr_point*)in_d, 0, c->ws.n_valid, 1, n_in, used, 1.0, dst, 0, c->ws.sor_n);
+    if (c->small_path && n_in <= kSmallMax) {  // 6 launches instead of ~32 (kernels/small.inc)
+        launch_sor_small(&c->prof, c->stream, c->ws, (const o3dr_point*)in_d, c->ws.n_valid, n_in, 1.0, dst, c->ws.sor_n);
+    } else {
+        const int used = launch_points_minmax(&c->prof, c->stream, (const o3dr_point*)in_d, 0, c->ws.n_valid, 1, n_in, c->ws.mm_stride, c->ws.mm);
+        launch_sor(&c->prof, c->stream, c->ws, (const o3dr_point*)in_d, 0, c->ws.n_valid, 1, n_in, used, 1.0, dst, 0, c->ws.sor_n);
+    }
     HIPCHK(hipGetLastError());
     uint32_t m = 0;
     CHK(read_u32(c, c->ws.sor_n, &m));

@@ -238,6 +238,11 @@ void launch_set_counts(Profiler* pf, hipStream_t s, uint32_t* n_dev, uint32_t va
 void launch_small_frame(Profiler* pf, hipStream_t s, const ReprojectArgs& a, const float* kp_xy, int n_kp, int downsample,
                         const float leaf[3], o3dr_point* pts, o3dr_point* out, CloudCounters* cc, uint32_t* n_out_dev,
                         float* box_out6);
+// statistical outlier removal of ONE cloud of at most kSmallMax points (n_dev[0] of them, cap >= that): preparation and
+// closing stages as one workgroup each around the unchanged search kernels (5 launches instead of 30); inliers -> out in
+// input order, their number -> n_out_dev[0]
+void launch_sor_small(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, const uint32_t* n_dev, int64_t cap,
+                      double stddev_mul, o3dr_point* out, uint32_t* n_out_dev);
 void launch_small_voxel(Profiler* pf, hipStream_t s, const o3dr_point* in, const uint32_t* n_in_dev, uint32_t n_in,
                         const float* box6, const float leaf[3], uint32_t min_points, float z_offset, o3dr_point* out,
                         CloudCounters* cc);

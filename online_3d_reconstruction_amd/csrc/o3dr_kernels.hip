@@ -97,6 +97,27 @@ void launch_small_frame(Profiler* pf, hipStream_t s, const ReprojectArgs& a, con
     k_small<<<1, kSmallThreads, 0, s>>>(a, sa);
 }
 
+void launch_sor_small(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in, const uint32_t* n_dev, int64_t cap,
+                      double stddev_mul, o3dr_point* out, uint32_t* n_out_dev)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    const int64_t cell_stride = (int64_t)ws.sor_max_cells + 1;
+    uint32_t max_cells = (uint32_t)(cap / 2 > 1024 ? cap / 2 : 1024);  // (as launch_sor: the grid is only a search structure)
+    if (max_cells > ws.sor_max_cells) max_cells = ws.sor_max_cells;
+    k_sor_small_prep<<<1, kSmallThreads, 0, s>>>(in, n_dev, max_cells, ws.sor_geom, ws.geom, ws.vals[0], ws.sor_cell_first, ws.sor_xyz,
+                                                 ws.sor_left_cnt);
+    k_sor_knn<<<dim3(cdiv64(cap, kWave), 1), kWave, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_first, cell_stride,
+                                                           ws.sor_geom, cap, ws.sor_dist, ws.sor_left, ws.sor_left_cnt);
+    int lg = cdiv64(cap, kWave * kSorLeftWaves);
+    if (lg > 1024) lg = 1024;
+    int zg = cdiv64((int64_t)max_cells, 256);
+    if (zg > 256) zg = 256;
+    k_sor_cell_z<<<dim3(zg, 1), 256, 0, s>>>(ws.sor_xyz, ws.sor_cell_first, cell_stride, ws.sor_geom, cap, ws.sor_left_cnt, ws.sor_cell_z);
+    k_sor_knn_left<<<dim3(lg, 1), kSorLeftWaves * kWave, 0, s>>>(ws.sor_xyz, ws.vals[0], ws.vals[1], ws.geom, ws.sor_cell_first, cell_stride,
+                                                                ws.sor_geom, cap, ws.sor_dist, ws.sor_left, ws.sor_left_cnt, ws.sor_cell_z);
+    k_sor_small_tail<<<1, kSmallThreads, 0, s>>>(in, ws.sor_dist, ws.sor_geom, stddev_mul, out, n_out_dev);
+}
+
 void launch_small_voxel(Profiler* pf, hipStream_t s, const o3dr_point* in, const uint32_t* n_in_dev, uint32_t n_in,
                         const float* box6, const float leaf[3], uint32_t min_points, float z_offset, o3dr_point* out,
                         CloudCounters* cc)
@@ -462,10 +483,18 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
     const int tm = tm_lds <= 48 * 1024 ? 1 : 0;
     const int n_tiles = cdiv64(cap, 1024);
     const int64_t cell_stride = (int64_t)ws.sor_max_cells + 1;
-    k_sor_plan<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, mm_used, n_dev, ws.sor_max_cells, ws.sor_geom, ws.geom);
+    // The search grid never has more cells than points / 2 (and at least 1024): the cell ids of clouds of at most `cap`
+    // points need ceil(log2(max_cells) / 7) sort passes, and only those are launched (a --jump_pixels 15 frame: 2 instead of
+    // 5 launch groups that find nothing to do).  The grid is a search structure: the neighbours found do not depend on it.
+    uint32_t max_cells = (uint32_t)(cap / 2 > 1024 ? cap / 2 : 1024);
+    if (max_cells > ws.sor_max_cells) max_cells = ws.sor_max_cells;
+    int cell_bits = 1;
+    while ((1u << cell_bits) < max_cells) ++cell_bits;
+    const int sort_passes = (cell_bits + kMaxRadixBits - 1) / kMaxRadixBits;
+    k_sor_plan<<<F, 256, 0, s>>>(ws.mm, ws.mm_stride, mm_used, n_dev, max_cells, ws.sor_geom, ws.geom);
     (void)hipMemsetAsync(ws.sor_cell_first, 0, (size_t)F * (size_t)cell_stride * 4, s);
     k_sor_cells<<<dim3(cdiv64(cap, 256), F), 256, 0, s>>>(in, in_fstride, ws.sor_geom, cap, ws.keys[0]);
-    for (int pass = 0; pass < kMaxPasses; ++pass) {
+    for (int pass = 0; pass < sort_passes && pass < kMaxPasses; ++pass) {
         k_radix_hist<<<dim3(n_sort_tiles, F), kSortThreads, 0, s>>>(ws.keys[0], ws.keys[1], cap, ws.geom, pass, n_sort_tiles, ws.hist,
                                                                     ws.hist_part, tm);
         if (tm)

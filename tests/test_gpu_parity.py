@@ -284,6 +284,21 @@ def test_small_clouds_one_launch_path_equals_the_general_path_and_the_oracle(orc
         assert len(fast.createAndTransformPtCloud(empty, bgr, _pose(1))) == 0
         assert_points_equal(fast.createAndTransformPtCloud(one, bgr, _pose(1)), slow.createAndTransformPtCloud(one, bgr, _pose(1)), "one point")
         assert len(fast.createAndTransformPtCloud(one, bgr, _pose(1))) == 1
+        # the outlier removal alone and in front of the per-frame grid, small clouds (preparation and closing stages as one
+        # workgroup each around the unchanged search kernels): inliers, their order and the grid's output
+        for n in (40, 51, 52, 700, 4096, 4097, 8192):
+            pts = random_cloud(n, 700 + n, extent=(1.5, 1.0, 0.05))
+            pts["z"][:: 37] += np.float32(0.4)  # a few outliers
+            ref, _ = orc.statistical_outlier_removal(pts)
+            a = fast.statisticalOutlierRemoval(pts)
+            assert_points_equal(a, slow.statisticalOutlierRemoval(pts), f"outlier removal small vs general path, n {n}")
+            assert_points_equal(a, ref, f"outlier removal small path vs oracle, n {n}")
+            prm = _params(voxel_size=0.05, sor_enable=True)
+            fast.set_params(prm)
+            slow.set_params(prm)
+            b = fast.downsamplePtCloud(pts, False)
+            assert_points_equal(b, slow.downsamplePtCloud(pts, False), f"downsamplePtCloud with outlier removal, small vs general, n {n}")
+            assert_points_equal(b, orc.downsample_pt_cloud(ref, 0.05, False, 1)[0], f"downsamplePtCloud with outlier removal vs oracle, n {n}")
         # whole-cloud calls on small clouds
         for n in (1, 2, 63, 64, 65, 1000, 4097, 8191, 8192, 8193):
             pts = random_cloud(n, 900 + n, extent=(1.2, 0.9, 0.4))
@@ -517,7 +532,7 @@ def test_full_size_configs2_2000_dense_frames_through_size_independent_propertie
     vs = np.float32(0.05)
 
     def cells(c):
-        return np.floor(c["y"] / vs).astype(np.int64) * (1 << 32) + (np.floor(c["x"] / vs).astype(np.int64) & 0xffffffff)
+        return np.floor(c["y"] / vs).astype(np.int64) * (1 << 32) + np.floor(c["x"] / vs).astype(np.int64)  # (y, then x: PCL's order)
 
     full = o3dr.Context(0, Q=Qs, params=prm)
     part = o3dr.Context(0, Q=Qs, params=prm)
