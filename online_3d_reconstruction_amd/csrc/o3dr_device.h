@@ -45,7 +45,11 @@ constexpr int kGroupBits = 5;
 constexpr int kGroupCells = 1 << kGroupBits;
 static_assert(kGroupCells <= kWave, "one lane per voxel of a group");
 constexpr int kGroupWaves = 4;            // groups per workgroup of k_centroid_groups
-constexpr int kGroupMinRun = 8;           // grouped records are used when they average at least this many points
+// grouped records are used when the runs average at least kGroupMinRunNum / kGroupMinRunDen points.  Round 4 measured the
+// break-even again (round 2 had set 8): forced on BASELINE configs[4]'s shape (4.1 points per run) 9.03 -> 6.94 ms per
+// 200-frame step, on configs[3]'s (raw pixel-order points, 1.6 per run) 9.49 -> 7.75 ms - the run sort moves fewer
+// records and k_centroid_groups reads the cloud once, coalesced, where k_centroid gathers 16 bytes per 64-byte sector
+constexpr int kGroupMinRunNum = 5, kGroupMinRunDen = 4;
 constexpr int64_t kGroupMinCloud = 1 << 20;  // whole-cloud calls on fewer points sort the points
 constexpr int64_t kGroupMinSlots = 1 << 20;  // result slots (16 bytes each) a context always has for the grouped path
 
