@@ -268,14 +268,30 @@ int o3dr_cloud_big_adopt(o3dr_ctx* ctx, int64_t n_points);
  * o3dr_cloud_big_assume_size: the caller read its own header back (with the all-to-all's sizes) and tells the library
  * the exact size of cloud_big, so that o3dr_cloud_big_view / o3dr_finalize* need no round trip of their own for it. */
 int o3dr_cloud_big_header_dev(o3dr_ctx* ctx, void* hdr_dev);
+/* The partition in two halves, so that a rank's own points move ONCE and are never sent to itself (round 4; what
+ * o3dr_merge_partitioned and dist.merge_partitioned use):
+ *   o3dr_cloud_big_slice_counts_dev - like o3dr_cloud_big_partition_dev, but nothing moves: n_parts int64 slice sizes + the
+ *     status word in the DEVICE buffer counts_dev; the (slice, tile) table stays in the workspace;
+ *   o3dr_cloud_big_place_slices - after the ranks exchanged their counts: `counts` = this rank's n_parts slice sizes (host),
+ *     n_before / n_after = points it will receive from lower / higher ranks.  One pass lays cloud_big out as
+ *     [n_before free | own slice | n_after free | the slices that leave, in rank order]; *send_offset = where those start.
+ *     A rank that neither sends nor receives keeps its cloud untouched.  The exchange then receives straight into the gaps
+ *     (o3dr_cloud_big_raw_view: address and capacity of the buffer) and o3dr_cloud_big_set_size(n_before + own + n_after)
+ *     makes that prefix the cloud (stream-ordered, like o3dr_cloud_big_adopt). */
+int o3dr_cloud_big_slice_counts_dev(o3dr_ctx* ctx, const void* hdrs_dev, int32_t n_hdrs, int32_t n_parts, int64_t* counts_dev);
+int o3dr_cloud_big_place_slices(o3dr_ctx* ctx, int32_t n_parts, int32_t own_part, const int64_t* counts, int64_t n_before,
+                                int64_t n_after, int64_t* send_offset);
+int o3dr_cloud_big_set_size(o3dr_ctx* ctx, int64_t n_points);
+int o3dr_cloud_big_raw_view(o3dr_ctx* ctx, void** ptr, int64_t* capacity_points);
 int o3dr_cloud_big_assume_size(o3dr_ctx* ctx, int64_t n_points);
 int o3dr_cloud_big_partition_dev(o3dr_ctx* ctx, const void* hdrs_dev, int32_t n_hdrs, int32_t n_parts, int64_t* counts_dev);
 
 /* The whole exchange in ONE call, for C++ hosts (the reference's merge sits in its C++ main flow, pose.cpp:527-532): one
  * host thread and one context per GPU, `nccl_comm` = that GPU's ncclComm_t (RCCL over xGMI; libo3dr resolves RCCL with
  * dlopen at first use and has no link-time dependency on it).  Steps (1)-(4) above with the small data kept in HBM (two
- * all-gathers of a few bytes, ONE host read-back, one grouped send/receive all-to-all out of cloud_big into the second
- * cloud buffer, the local merge over the global box), then, with gather_result != 0, an all-gather of the merged
+ * all-gathers of a few bytes, ONE host read-back, the slices placed in one pass, one grouped send/receive all-to-all
+ * straight into the gaps left for it - the rank's own slice is not sent -, the local merge over the global box), then,
+ * with gather_result != 0, an all-gather of the merged
  * slices: `out` receives the whole merged cloud (the single-GPU result, bit for bit); with gather_result == 0 this
  * rank's slice.  A rank that does not want the result passes out = NULL, out_capacity = 0 (it still takes part in every
  * collective).  *n_total = points merged over all ranks.  Must be called by all ranks of the communicator.

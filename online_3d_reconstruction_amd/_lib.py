@@ -77,6 +77,10 @@ SYMBOLS = [
     ("o3dr_cloud_big_header_dev", C.c_int, [_vp, _vp]),
     ("o3dr_cloud_big_assume_size", C.c_int, [_vp, _i64]),
     ("o3dr_cloud_big_partition_dev", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    ("o3dr_cloud_big_slice_counts_dev", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    ("o3dr_cloud_big_place_slices", C.c_int, [_vp, _i32, _i32, _vp, _i64, _i64, _pi64]),
+    ("o3dr_cloud_big_set_size", C.c_int, [_vp, _i64]),
+    ("o3dr_cloud_big_raw_view", C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     ("o3dr_merge_partitioned", C.c_int, [_vp, _vp, _i32, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_uint32), _i32]),
     ("o3dr_merge_partitioned_stats", C.c_int, [_vp, _pi64]),
     ("o3dr_cloud_big_capacity", C.c_int, [_vp, _pi64, _pi64]),

@@ -390,6 +390,35 @@ class Context:
         self._keep = hdrs  # (the launches read it)
         return counts
 
+    def cloudBigSliceCountsDev(self, hdrs, n_parts):
+        """hdrs: the all-gathered headers ([world*32] uint8, CUDA).  Slice sizes of cloud_big over the box the headers span,
+        NOTHING MOVED: -> int64 CUDA tensor [n_parts + 1] (sizes, then the status word).  Asynchronous."""
+        import torch
+        assert hdrs.is_cuda and hdrs.is_contiguous() and hdrs.numel() % 32 == 0
+        counts = torch.empty(n_parts + 1, dtype=torch.int64, device=hdrs.device)
+        self._order_after_torch()
+        L.check(self._lib.o3dr_cloud_big_slice_counts_dev(self._h, hdrs.data_ptr(), hdrs.numel() // 32, int(n_parts), counts.data_ptr()))
+        self._keep = hdrs  # (the launches read it)
+        return counts
+
+    def cloudBigPlaceSlices(self, own_part, counts, n_before, n_after):
+        """lay cloud_big out as [n_before free | own slice | n_after free | leaving slices]; -> offset of the leaving slices"""
+        arr = (C.c_int64 * len(counts))(*[int(v) for v in counts])
+        off = C.c_int64(0)
+        L.check(self._lib.o3dr_cloud_big_place_slices(self._h, len(counts), int(own_part), arr, int(n_before), int(n_after), C.byref(off)))
+        return off.value
+
+    def cloudBigSetSize(self, n_points):
+        """the first n_points of the cloud buffer are the cloud (after the exchange filled the gaps); stream-ordered"""
+        L.check(self._lib.o3dr_cloud_big_set_size(self._h, int(n_points)))
+
+    def cloudBigRawView(self):
+        """[capacity,4] int32 CUDA tensor over the whole cloud buffer (valid until the next call that may reallocate it)"""
+        ptr = C.c_void_p()
+        cap = C.c_int64(0)
+        L.check(self._lib.o3dr_cloud_big_raw_view(self._h, C.byref(ptr), C.byref(cap)))
+        return _device_tensor(ptr.value, cap.value, self.device)
+
     def cloudBigCapacity(self):
         """(points cloud_big holds, points the receive buffer holds) without reallocating"""
         a, b = C.c_int64(0), C.c_int64(0)

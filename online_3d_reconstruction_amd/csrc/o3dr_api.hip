@@ -129,6 +129,8 @@ struct o3dr_ctx {
     int test_corrupt = 0;  // o3dr_test_corrupt_next_gather: consumed by the next voxel grid
     int test_fail_at = 0;  // o3dr_test_fail_at: the numbered step of the next o3dr_merge_partitioned fails on this rank
     int64_t xchg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // o3dr_merge_partitioned_stats
+    int64_t place_ub = -1;   // o3dr_cloud_big_slice_counts_dev ran for a cloud of at most this many points and place_parts slices:
+    int place_parts = 0;     // the (slice, tile) table in the workspace is what o3dr_cloud_big_place_slices moves by
     int test_hooks = 0;    // O3DR_TEST_HOOKS=1 at o3dr_ctx_create: the entry points of include/o3dr_testing.h act
     int host_batch = 32;  // frames per upload while the previous batch computes (O3DR_HOST_BATCH_FRAMES)
     Profiler prof;
@@ -1721,6 +1723,123 @@ extern "C" int o3dr_cloud_big_partition_dev(o3dr_ctx* c, const void* hdrs_dev, i
     return O3DR_OK;
 }
 
+// ---- the partition in two halves: slice sizes first (nothing moves), then ONE pass that places the slices where the
+// exchange wants them - [room for what the lower ranks send | this rank's own slice | room for the higher ranks' | the
+// slices that leave, in rank order] - so that the all-to-all receives straight into the gaps and the own slice (95 % of the
+// cloud at the benchmark shapes) is never sent to itself
+static int slice_args(o3dr_ctx* c, VoxelArgs& v, int64_t ub)
+{
+    float leaf[3], zo;
+    uint32_t mp;
+    downsample_leaf(c->params, 1, leaf, &mp, &zo);
+    memset(&v, 0, sizeof v);
+    v.in = c->cloud_big;
+    v.n_dev = c->ws.n_valid;
+    v.frames = 1;
+    v.cap = ub;
+    v.leaf[0] = leaf[0];
+    v.leaf[1] = leaf[1];
+    v.leaf[2] = leaf[2];
+    v.z_offset = zo;
+    return O3DR_OK;
+}
+extern "C" int o3dr_cloud_big_slice_counts_dev(o3dr_ctx* c, const void* hdrs_dev, int32_t n_hdrs, int32_t n_parts, int64_t* counts_dev)
+{
+    CTX_ENTER(c);
+    if (!hdrs_dev || !counts_dev || n_hdrs < 1 || n_parts < 1 || n_parts > kMaxRadix)
+        return fail(O3DR_ERR_INVALID_ARG, "bad arguments (1 <= n_parts <= 128)");
+    c->place_ub = -1;
+    HIPCHK(hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * ((size_t)n_parts + 1), c->stream));
+    const int64_t ub = c->cloud_ub;  // kernels take the count from the device; the bound sizes grids and buffers
+    if (ub == 0 || !c->cloud_big) {
+        c->place_ub = 0;
+        c->place_parts = n_parts;
+        return O3DR_OK;
+    }
+    if (ub >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+    CHK(ws_ensure(c, 1, ub, false));
+    launch_count_from_cc(c->stream, c->cc_big, c->ws.n_valid);
+    VoxelArgs v;
+    CHK(slice_args(c, v, ub));
+    launch_partition_count(&c->prof, c->stream, c->ws, v, n_parts, (uint64_t*)counts_dev, (uint32_t*)(counts_dev + n_parts), hdrs_dev, n_hdrs);
+    if (hipGetLastError() != hipSuccess) return fail(O3DR_ERR_HIP, "slice count launch failed");
+    c->place_ub = ub;
+    c->place_parts = n_parts;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_place_slices(o3dr_ctx* c, int32_t n_parts, int32_t own_part, const int64_t* counts, int64_t n_before,
+                                           int64_t n_after, int64_t* send_offset)
+{
+    CTX_ENTER(c);
+    if (!counts || n_parts < 1 || n_parts > kMaxRadix || own_part < 0 || own_part >= n_parts || n_before < 0 || n_after < 0)
+        return fail(O3DR_ERR_INVALID_ARG, "bad arguments");
+    if (c->place_ub < 0 || c->place_parts != n_parts) return fail(O3DR_ERR_INVALID_ARG, "o3dr_cloud_big_slice_counts_dev must run first, for the same slices");
+    int64_t n_local = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        if (counts[p] < 0) return fail(O3DR_ERR_INVALID_ARG, "negative slice size");
+        n_local += counts[p];
+    }
+    if (n_local > c->place_ub) return fail(O3DR_ERR_INVALID_ARG, "slice sizes above the cloud's size");
+    const int64_t own = counts[own_part], send_start = n_before + own + n_after, total = send_start + (n_local - own);
+    if (send_offset) *send_offset = send_start;
+    const int64_t cap_counted = c->place_ub;  // the (slice, tile) table is laid out for this many points: the move must use the same tiling
+    c->place_ub = -1;                         // (the table is consumed)
+    if (n_before == 0 && n_after == 0 && own == n_local) return O3DR_OK;  // nothing leaves, nothing arrives: the cloud stays as it is
+    if (total >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "the exchange buffer exceeds 2^32-1 points");
+    CHK(alt_reserve(c, total > 0 ? total : 1));
+    // part p's records start at sum(counts[0..p)) in the plain layout; where they go instead
+    int64_t* sh = (int64_t*)(c->misc_host + 2560);
+    int64_t nat = 0, out_off = send_start;
+    for (int p = 0; p < n_parts; ++p) {
+        if (p == own_part) {
+            sh[p] = n_before - nat;
+        } else {
+            sh[p] = out_off - nat;
+            out_off += counts[p];
+        }
+        nat += counts[p];
+    }
+    HIPCHK(hipMemcpyAsync(c->misc_dev + 2560, sh, sizeof(int64_t) * (size_t)n_parts, hipMemcpyHostToDevice, c->stream));
+    if (n_local > 0) {
+        VoxelArgs v;
+        CHK(slice_args(c, v, cap_counted));
+        launch_partition_move(&c->prof, c->stream, c->ws, v, n_parts, c->cloud_alt, (const int64_t*)(c->misc_dev + 2560));
+        if (hipGetLastError() != hipSuccess) return fail(O3DR_ERR_HIP, "slice placement launch failed");
+        // (the pinned shift table is only written here, and every exchange ends in a stream wait - the merged slice's size -
+        // before the next one can begin)
+    }
+    swap_clouds(c);  // the laid-out copy becomes cloud_big (its device count is stale until o3dr_cloud_big_set_size)
+    c->cloud_box_valid = false;
+    c->cloud_heads_valid = false;
+    c->cloud_ub = total;
+    c->cloud_n_exact = false;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_set_size(o3dr_ctx* c, int64_t n_points)
+{
+    CTX_ENTER(c);
+    if (n_points < 0 || n_points > c->cloud_cap) return fail(O3DR_ERR_INVALID_ARG, "more points than the cloud buffer holds");
+    if (n_points >= (int64_t)0xffffffffLL) return fail(O3DR_ERR_INVALID_ARG, "cloud_big exceeds 2^32-1 points");
+    launch_set_cloud_count(c->stream, c->cc_big, (uint64_t)n_points);  // stream-ordered, like o3dr_cloud_big_adopt
+    HIPCHK(hipGetLastError());
+    c->cloud_box_valid = false;
+    c->cloud_heads_valid = false;
+    c->cloud_ub = n_points;
+    c->cloud_n_exact = true;
+    return O3DR_OK;
+}
+
+extern "C" int o3dr_cloud_big_raw_view(o3dr_ctx* c, void** ptr, int64_t* capacity_points)
+{
+    CTX_ENTER(c);
+    if (!ptr || !capacity_points) return fail(O3DR_ERR_INVALID_ARG, "ptr / capacity is NULL");
+    *ptr = c->cloud_big;
+    *capacity_points = c->cloud_cap;
+    return O3DR_OK;
+}
+
 extern "C" int o3dr_cloud_big_bbox(o3dr_ctx* c, float mn[3], float mx[3], int64_t* n_out)
 {
     CTX_ENTER(c);
@@ -1888,9 +2007,10 @@ struct Transport {
     virtual ~Transport() {}
     // every rank contributes `bytes` at send_dev; recv_dev receives W * bytes in rank order (ordered on c->stream)
     virtual int all_gather(o3dr_ctx* c, const void* send_dev, void* recv_dev, size_t bytes) = 0;
-    // send[p] points starting at send_base + sum(send[0..p)) go to rank p; recv[p] points from rank p land at
-    // recv_base + sum(recv[0..p)): segments arrive in source-rank order
-    virtual int all_to_all(o3dr_ctx* c, const o3dr_point* send_base, const int64_t* send, o3dr_point* recv_base, const int64_t* recv) = 0;
+    // send[p] points at base + send_off[p] go to rank p; recv[p] points from rank p land at base + recv_off[p] (same buffer,
+    // disjoint regions).  Nothing is sent to the rank itself: its own slice is already where it belongs.
+    virtual int all_to_all(o3dr_ctx* c, o3dr_point* base, const int64_t* send_off, const int64_t* send, const int64_t* recv_off,
+                           const int64_t* recv) = 0;
 };
 
 struct RcclTransport : Transport {
@@ -1901,18 +2021,17 @@ struct RcclTransport : Transport {
         NCCLCHK(R, R->AllGather(send_dev, recv_dev, bytes, ncclUint8, comm, c->stream));
         return O3DR_OK;
     }
-    int all_to_all(o3dr_ctx* c, const o3dr_point* send_base, const int64_t* send, o3dr_point* recv_base, const int64_t* recv) override
+    int all_to_all(o3dr_ctx* c, o3dr_point* base, const int64_t* send_off, const int64_t* send, const int64_t* recv_off,
+                   const int64_t* recv) override
     {
         // every peer pair has its own xGMI link.  An error inside the group must not leave it open: ncclGroupEnd is
         // always reached, the first error is reported after it.
         NCCLCHK(R, R->GroupStart());
         ncclResult_t first = ncclSuccess;
-        int64_t soff = 0, roff = 0;
         for (int p = 0; p < W; ++p) {
-            if (send[p] && first == ncclSuccess) first = R->Send(send_base + soff, (size_t)send[p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream);
-            if (recv[p] && first == ncclSuccess) first = R->Recv(recv_base + roff, (size_t)recv[p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream);
-            soff += send[p];
-            roff += recv[p];
+            if (p == rank) continue;
+            if (send[p] && first == ncclSuccess) first = R->Send(base + send_off[p], (size_t)send[p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream);
+            if (recv[p] && first == ncclSuccess) first = R->Recv(base + recv_off[p], (size_t)recv[p] * sizeof(o3dr_point), ncclUint8, p, comm, c->stream);
         }
         const ncclResult_t endr = R->GroupEnd();
         NCCLCHK(R, first);
@@ -1929,7 +2048,7 @@ struct LocalComm {  // test transport: shared by the W rank threads
     uint64_t generation = 0;
     bool broken = false;
     std::vector<const void*> ptr;
-    std::vector<const int64_t*> cnt;
+    std::vector<const int64_t*> cnt, off;
     // false: a rank did not show up within 30 s (it left the protocol: exactly what the tests look for)
     bool barrier()
     {
@@ -1963,22 +2082,21 @@ struct LocalTransport : Transport {
         if (!L->barrier()) return fail(O3DR_ERR_PEER, "local transport: a rank left the exchange (all-gather)");
         return O3DR_OK;
     }
-    int all_to_all(o3dr_ctx* c, const o3dr_point* send_base, const int64_t* send, o3dr_point* recv_base, const int64_t* recv) override
+    int all_to_all(o3dr_ctx* c, o3dr_point* base, const int64_t* send_off, const int64_t* send, const int64_t* recv_off,
+                   const int64_t* recv) override
     {
         HIPCHK(hipStreamSynchronize(c->stream));
-        L->ptr[(size_t)rank] = send_base;
+        L->ptr[(size_t)rank] = base;
         L->cnt[(size_t)rank] = send;
+        L->off[(size_t)rank] = send_off;
         if (!L->barrier()) return fail(O3DR_ERR_PEER, "local transport: a rank left the exchange (all-to-all)");
-        int64_t roff = 0;
         int rc = O3DR_OK;
         for (int p = 0; p < W && rc == O3DR_OK; ++p) {
-            int64_t soff = 0;
-            for (int q = 0; q < rank; ++q) soff += L->cnt[(size_t)p][q];
+            if (p == rank) continue;
             if (L->cnt[(size_t)p][rank] != recv[p]) rc = fail(O3DR_ERR_INTERNAL, "local transport: send and receive counts differ");
-            else if (recv[p] && hipMemcpyAsync(recv_base + roff, (const o3dr_point*)L->ptr[(size_t)p] + soff, (size_t)recv[p] * sizeof(o3dr_point),
-                                               hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            else if (recv[p] && hipMemcpyAsync(base + recv_off[p], (const o3dr_point*)L->ptr[(size_t)p] + L->off[(size_t)p][rank],
+                                               (size_t)recv[p] * sizeof(o3dr_point), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
                 rc = fail(O3DR_ERR_HIP, "local transport: copy failed");
-            roff += recv[p];
         }
         if (hipStreamSynchronize(c->stream) != hipSuccess && rc == O3DR_OK) rc = fail(O3DR_ERR_HIP, "local transport: sync failed");
         if (!L->barrier()) return fail(O3DR_ERR_PEER, "local transport: a rank left the exchange (all-to-all)");
@@ -2060,8 +2178,8 @@ static int merge_partitioned_impl(o3dr_ctx* c, Transport& T, int32_t gather_resu
         HIPCHK(hipStreamSynchronize(c->stream));  // (the pinned word is reused below)
     }
     CHK(T.all_gather(c, d + o_hdr, d + o_hdrs, 32));
-    // 2. partition against the box the headers span
-    if (local == O3DR_OK) note(injected(2) ? O3DR_ERR_ALLOC : o3dr_cloud_big_partition_dev(c, d + o_hdrs, W, W, (int64_t*)(d + o_row)));
+    // 2. slice sizes over the box the headers span (nothing moves yet: the slices are placed once the counts are known)
+    if (local == O3DR_OK) note(injected(2) ? O3DR_ERR_ALLOC : o3dr_cloud_big_slice_counts_dev(c, d + o_hdrs, W, W, (int64_t*)(d + o_row)));
     if (local != O3DR_OK) HIPCHK(hipMemsetAsync(d + o_row, 0, 8 * ((size_t)W + 1), c->stream));
     int64_t* extra = (int64_t*)c->xchg_host;
     extra[0] = (int64_t)local;
@@ -2125,18 +2243,30 @@ static int merge_partitioned_impl(o3dr_ctx* c, Transport& T, int32_t gather_resu
     c->xchg_stats[4] = c->xchg_stats[2] * (int64_t)sizeof(o3dr_point);
     c->xchg_stats[5] = n_recv;                                                         // points entering this rank's merge
     c->xchg_stats[7] = total_pts;
+    // Where this rank's points go: its own slice stays with it, placed once with room in front for what the lower ranks
+    // send and behind for the higher ranks'; the slices that leave follow.  A rank that neither sends nor receives
+    // anything keeps its cloud as it is (its recorded box and run heads stay valid).
+    auto placed = [&](int r, int64_t& off_rank, int64_t& nr) {  // points rank r's exchange buffer must hold (0: nothing moves there)
+        nr = 0;
+        for (int p = 0; p < W; ++p) nr += sends(p, r);
+        off_rank = hdrs[r].count - sends(r, r);
+        return (off_rank == 0 && nr == sends(r, r)) ? (int64_t)0 : nr + off_rank;
+    };
+    int64_t n_off = 0, nr_me = 0;
+    const int64_t need_alt = overflow ? 0 : placed(rank, n_off, nr_me);
+    const bool moves = need_alt != 0;
     // does any rank have to grow a buffer before the all-to-all?  (every rank evaluates every rank: no disagreement)
     bool any_grows = false;
     for (int r = 0; r < W; ++r) {
-        int64_t nr = 0;
-        for (int p = 0; p < W; ++p) nr += sends(p, r);
+        int64_t o_r = 0, n_r = 0;
+        const int64_t need_r = overflow ? 0 : placed(r, o_r, n_r);
         const int64_t* ex = mat + (size_t)r * RW + W + 2;
-        any_grows = any_grows || (!overflow && nr > ex[0]) || max_slice > ex[1] || (gather_result && (int64_t)W * pad_bound > ex[2]);
+        any_grows = any_grows || need_r > ex[0] || max_slice > ex[1] || (gather_result && (int64_t)W * pad_bound > ex[2]);
     }
     if (any_grows) {
         int rc = O3DR_OK;
         if (injected(3)) rc = O3DR_ERR_ALLOC;
-        if (rc == O3DR_OK && !overflow) rc = alt_reserve(c, n_recv > 0 ? n_recv : 1);
+        if (rc == O3DR_OK && need_alt > 0) rc = alt_reserve(c, need_alt);
         if (rc == O3DR_OK) rc = dev_ensure(c, c->st_merge, (size_t)(max_slice > 0 ? max_slice : 1) * sizeof(o3dr_point));
         if (rc == O3DR_OK && gather_result) rc = dev_ensure(c, c->st_gather, (size_t)W * (size_t)(pad_bound > 0 ? pad_bound : 1) * sizeof(o3dr_point));
         note(rc);
@@ -2152,9 +2282,27 @@ static int merge_partitioned_impl(o3dr_ctx* c, Transport& T, int32_t gather_resu
     c->cloud_ub = n_local;  // (its own header told the host)
     c->cloud_n_exact = true;
     if (!overflow) {
-        // all-to-all out of cloud_big into the second cloud buffer; segments land in source-rank order = global frame order
-        CHK(T.all_to_all(c, c->cloud_big, send.data(), c->cloud_alt, recv.data()));
-        CHK(o3dr_cloud_big_adopt(c, n_recv));
+        // one pass places the slices; the all-to-all then receives straight into the gaps (every peer pair has its own
+        // xGMI link; segments land in source-rank order = global frame order); the own slice is never sent
+        int64_t n_before = 0, n_after = 0;
+        for (int p = 0; p < W; ++p) (p < rank ? n_before : n_after) += p == rank ? 0 : recv[(size_t)p];
+        std::vector<int64_t> send_off((size_t)W, 0), recv_off((size_t)W, 0), send_x(send), recv_x(recv);
+        send_x[(size_t)rank] = recv_x[(size_t)rank] = 0;
+        if (moves) {
+            int64_t send_start = 0;
+            CHK(o3dr_cloud_big_place_slices(c, W, rank, send.data(), n_before, n_after, &send_start));
+            int64_t so = send_start, lo = 0, hi = n_before + send[(size_t)rank];
+            for (int p = 0; p < W; ++p) {
+                if (p == rank) continue;
+                send_off[(size_t)p] = so;
+                so += send[(size_t)p];
+                int64_t& ro = p < rank ? lo : hi;
+                recv_off[(size_t)p] = ro;
+                ro += recv[(size_t)p];
+            }
+        }
+        CHK(T.all_to_all(c, c->cloud_big, send_off.data(), send_x.data(), recv_off.data(), recv_x.data()));
+        if (moves) CHK(o3dr_cloud_big_set_size(c, n_recv));
     }
     // 4. local merge of the slice over the global box (the second host wait: its size).  A failure here travels with
     //    the merged sizes of the final gather, so that no rank waits in a collective the failed one never enters.
@@ -2251,6 +2399,7 @@ extern "C" int o3dr_test_local_comm_create(int32_t n_ranks, void** comm_out)
     L->W = n_ranks;
     L->ptr.assign((size_t)n_ranks, nullptr);
     L->cnt.assign((size_t)n_ranks, nullptr);
+    L->off.assign((size_t)n_ranks, nullptr);
     *comm_out = L;
     return O3DR_OK;
 }

@@ -267,6 +267,12 @@ int launch_sor(Profiler* pf, hipStream_t s, Workspace& ws, const o3dr_point* in,
                uint32_t* n_out_dev);
 void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
                       uint64_t* counts_dev, uint32_t* overflow_dev, const void* hdrs_dev = nullptr, int n_hdrs = 0);
+// its two halves: slice sizes without moving anything (the (part, tile) table stays in ws for the second half), then the move
+// with part p's records shifted by part_shift_dev[p] against the plain "parts one after the other" layout
+void launch_partition_count(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, uint64_t* counts_dev,
+                            uint32_t* overflow_dev, const void* hdrs_dev = nullptr, int n_hdrs = 0);
+void launch_partition_move(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
+                           const int64_t* part_shift_dev);
 // the exchange's small data, kept on the device (kernels/multigpu.inc)
 void launch_pack_header(hipStream_t s, const float* box6_dev, const CloudCounters* cc, void* hdr32_dev);
 void launch_count_from_cc(hipStream_t s, const CloudCounters* cc, uint32_t* n_dev);

@@ -452,8 +452,10 @@ void launch_count_from_cc(hipStream_t s, const CloudCounters* cc, uint32_t* n_de
 void launch_set_cloud_count(hipStream_t s, CloudCounters* cc, uint64_t n) { k_set_cloud_count<<<1, 1, 0, s>>>(cc, n); }
 
 // hdrs_dev (optional): the box in ws.mm slot 0 is first folded from n_hdrs 32-byte rank headers in HBM
-void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
-                      uint64_t* counts_dev, uint32_t* overflow_dev, const void* hdrs_dev, int n_hdrs)
+// the two halves of the stable partition by index slice: counts per (part, tile) + their scan (ws.hist, ws.geom: kept for the
+// second half) and the slice sizes; then the move, optionally with a shift per part (k_part_move)
+void launch_partition_count(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, uint64_t* counts_dev,
+                            uint32_t* overflow_dev, const void* hdrs_dev, int n_hdrs)
 {
     const int64_t cap = v.cap;
     const int n_sort_tiles = cdiv64(cap, kSortTile);
@@ -461,12 +463,25 @@ void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArg
     ProfScope ps(pf, O3DR_K_OTHER, s);
     if (hdrs_dev) k_fold_headers<<<1, 1, 0, s>>>(reinterpret_cast<const CloudHeader*>(hdrs_dev), n_hdrs, ws.mm);
     k_voxel_geom<<<1, 256, 0, s>>>(ws.mm, ws.mm_stride, 1, v.n_dev, v.leaf[0], v.leaf[1], v.leaf[2], v.z_offset, ws.geom);
-    // count per (part, tile), scan, move the points (two reads and one write of the cloud); n_parts <= kMaxRadix
+    // count per (part, tile), scan; n_parts <= kMaxRadix
     k_part_plan<<<1, 1, 0, s>>>(ws.geom, n_parts);
     k_part_count<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist);
     launch_scan(s, ws.hist, hist_row, hist_row, 1, nullptr, nullptr, ws.scan_partial, ws.geom, 0, n_sort_tiles);
-    k_part_move<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist, out);
     k_part_counts_scanned<<<cdiv64(n_parts, 64), 64, 0, s>>>(ws.hist, ws.geom, n_parts, n_sort_tiles, counts_dev, overflow_dev);
+}
+void launch_partition_move(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
+                           const int64_t* part_shift_dev)
+{
+    ProfScope ps(pf, O3DR_K_OTHER, s);
+    const int n_sort_tiles = cdiv64(v.cap, kSortTile);
+    k_part_move<<<n_sort_tiles, kSortThreads, 0, s>>>(v.in, ws.geom, v.z_offset, n_parts, n_sort_tiles, ws.hist, out, part_shift_dev);
+}
+void launch_partition(Profiler* pf, hipStream_t s, Workspace& ws, const VoxelArgs& v, int n_parts, o3dr_point* out,
+                      uint64_t* counts_dev, uint32_t* overflow_dev, const void* hdrs_dev, int n_hdrs)
+{
+    // (two reads and one write of the cloud)
+    launch_partition_count(pf, s, ws, v, n_parts, counts_dev, overflow_dev, hdrs_dev, n_hdrs);
+    launch_partition_move(pf, s, ws, v, n_parts, out, nullptr);
 }
 
 // Statistical outlier removal of a batch of clouds (see o3dr_device.h).  ws.sor_* are laid out for ws.sor_cap points

@@ -183,11 +183,18 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
     stats["collectives"] += 1
     # 2. partition (+ status word, this rank's error code, its receive buffer's capacity)
     row_head = None
+    # two_phase: slice sizes first (nothing moves), the slices placed in ONE pass once the counts are known, with room for
+    # what arrives in front of and behind the rank's own slice, which is then never sent to itself (include/o3dr.h)
+    two_phase = dev_path and comm_device is None and hasattr(ctx, "cloudBigPlaceSlices") and hasattr(ctx, "cloudBigRawView")
+    stats["two_phase"] = bool(two_phase)
     if dev_path:
         torch_to_lib()
         if local["code"] == 0:
             try:
-                row_head = ctx.cloudBigPartitionDev(hdrs, world)  # int64 [world + 1] in HBM, asynchronous
+                if two_phase:
+                    row_head = ctx.cloudBigSliceCountsDev(hdrs, world)  # int64 [world + 1] in HBM, asynchronous, nothing moved
+                else:
+                    row_head = ctx.cloudBigPartitionDev(hdrs, world)    # ... the cloud reordered by slice
             except Exception as e:  # noqa: BLE001
                 note(e)
         lib_to_torch()
@@ -243,12 +250,19 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
                   "points_received_off_rank": n_recv - recv_counts[rank], "bytes_sent": 16 * (n_local - counts[rank]),
                   "bytes_received": 16 * (n_recv - recv_counts[rank]), "points_into_merge": n_recv, "points_all_ranks": total})
     # does any rank have to grow its receive buffer?  (every rank evaluates every rank: no disagreement)
-    any_grows = bool((sends.sum(axis=0) > matrix_h[:, world + 2]).any()) and not overflow
+    n_off = n_local - counts[rank]
+    if two_phase:  # the buffer holds what arrives AND what leaves; a rank that neither sends nor receives moves nothing
+        off_all = hcounts.astype(np.int64) - np.diag(sends)
+        need_all = np.where((off_all == 0) & (sends.sum(axis=0) == np.diag(sends)), 0, sends.sum(axis=0) + off_all)
+    else:
+        need_all = sends.sum(axis=0)
+    need_mine = int(need_all[rank])
+    any_grows = bool((need_all > matrix_h[:, world + 2]).any()) and not overflow
     recv = None
     if any_grows:
         if zero_copy:
             try:
-                recv = ctx.cloudBigRecvBuffer(n_recv)
+                recv = ctx.cloudBigRecvBuffer(need_mine)
             except Exception as e:  # noqa: BLE001
                 note(e)
         ok = torch.empty(world, dtype=torch.int64, device=cdev)
@@ -261,7 +275,32 @@ def merge_partitioned(ctx, device, group=None, gather_result=True, comm_device=N
         for r in range(world):
             if ok_h[r] < 0:
                 leave(r, ok_h[r])
-    if zero_copy:
+    if two_phase and not overflow:
+        # the slices placed in one pass, with gaps for what arrives; two all-to-alls (to the higher ranks / to the lower ranks:
+        # each receives into ONE contiguous gap, which all_to_all_single needs) move only what changes rank
+        if hasattr(ctx, "cloudBigAssumeSize"):
+            ctx.cloudBigAssumeSize(n_local)
+        n_before, n_after, own = sum(recv_counts[:rank]), sum(recv_counts[rank + 1:]), counts[rank]
+        moves = need_mine != 0
+        empty = torch.empty((0, 4), dtype=torch.int32, device=device)
+        lo_out = hi_out = to_lo = to_hi = empty
+        if moves:
+            send_start = ctx.cloudBigPlaceSlices(rank, counts, n_before, n_after)
+            raw = ctx.cloudBigRawView()
+            n_lo = sum(counts[:rank])
+            lo_out, hi_out = raw[:n_before], raw[n_before + own: n_before + own + n_after]
+            to_lo, to_hi = raw[send_start: send_start + n_lo], raw[send_start + n_lo: send_start + n_off]
+        lib_to_torch()
+        zeros_lo, zeros_hi = [0] * (rank + 1), [0] * (world - rank)
+        dist.all_to_all_single(lo_out, to_hi, output_split_sizes=recv_counts[:rank] + zeros_hi,
+                               input_split_sizes=zeros_lo + counts[rank + 1:], group=group)
+        dist.all_to_all_single(hi_out, to_lo, output_split_sizes=zeros_lo + recv_counts[rank + 1:],
+                               input_split_sizes=counts[:rank] + zeros_hi, group=group)
+        stats["collectives"] += 2
+        torch_to_lib()
+        if moves:
+            ctx.cloudBigSetSize(n_recv)                     # stream-ordered
+    elif zero_copy:
         # send straight out of cloud_big, receive straight into the library's second cloud buffer
         if hasattr(ctx, "cloudBigAssumeSize"):
             ctx.cloudBigAssumeSize(n_local)                 # (its own header told the host: no round trip for the view)

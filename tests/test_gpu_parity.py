@@ -1009,7 +1009,10 @@ def test_zero_copy_exchange_single_rank_rccl(orc):
             assert total2 == total
             assert_points_equal(points_from_torch(merged), ref, "device-resident exchange after frame calls")
             st = dict(o3dist.last_stats)
-            assert st["device_resident"] and st["collectives"] == 5 and st["host_syncs_before_final_gather"] == 2, st
+            # (two-phase partition: sizes first, one placement, an all-to-all towards the higher and one towards the lower
+            # ranks - 6 collectives; with one rank nothing moves at all and the cloud stays where it is)
+            assert st["device_resident"] and st["two_phase"] and st["collectives"] == 6 and st["host_syncs_before_final_gather"] == 2, st
+            assert st["points_sent_off_rank"] == 0 and st["points_into_merge"] == total
         with o3dr.Context(0, Q=Qs, params=_params(jump_pixels=2, voxel_size=0.05)) as c:  # the context's own stream
             c.accumulateFrames(disp, bgr, poses)
             merged, _ = o3dist.merge_partitioned(c, dev)
