@@ -642,6 +642,92 @@ def test_partitioned_merge_virtual_ranks(Q, orc, world):
     assert min(sizes) > 0  # every slice got work
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_two_phase_partition_virtual_ranks(Q, world):
+    """The two-phase entry points driven by hand, `world` contexts standing in for as many ranks: slice sizes with nothing
+    moved (o3dr_cloud_big_slice_counts_dev), ONE placement as [gap | own slice | gap | leaving slices]
+    (o3dr_cloud_big_place_slices), the segments copied straight into the gaps of the raw buffers (what the all-to-all does),
+    o3dr_cloud_big_set_size, the merge over the global box: the concatenated slice merges equal the single-context merge,
+    bit for bit; the sizes equal the one-call partition's; a rank whose points all stay and that receives nothing is not
+    touched."""
+    import torch
+    import online_3d_reconstruction_amd as o3dr
+    from online_3d_reconstruction_amd import synth
+    from online_3d_reconstruction_amd.dist import shard_range, _parse_headers
+    F = 13
+    disp, bgr = synth.make_frames(340, F, invalid_frac=0.01)
+    poses = synth.make_poses(340, F)
+    prm = _params(jump_pixels=3, voxel_size=0.05)
+    Qs = synth.camera_Q()
+    with o3dr.Context(0, Q=Qs, params=prm) as one:
+        one.accumulateFrames(disp, bgr, poses)
+        ref = one.finalize()
+    ctxs = [o3dr.Context(0, Q=Qs, params=prm) for _ in range(world)]
+    try:
+        hdrs = []
+        for r, c in enumerate(ctxs):
+            a, b = shard_range(F, r, world)
+            if b > a:
+                c.accumulateFrames(disp[a:b], bgr[a:b], poses[a:b])
+            hdrs.append(c.cloudBigHeaderDev())
+        torch.cuda.synchronize()
+        all_hdrs = torch.cat(hdrs)
+        gmin, gmax, hcounts = _parse_headers(all_hdrs.cpu().numpy(), world)
+        rows = []
+        for c in ctxs:
+            row = c.cloudBigSliceCountsDev(all_hdrs, world)
+            c.synchronize()
+            row = [int(v) for v in row.cpu().tolist()]
+            assert row[world] == 0 and sum(row[:world]) == c.cloudBigSize()[0]
+            rows.append(row[:world])
+        sends = np.array(rows, np.int64)  # sends[s, r]
+        # the one-call partition of rounds 2-3 gives the same sizes (on a copy of rank 0's cloud)
+        with o3dr.Context(0, Q=Qs, params=prm) as chk:
+            a, b = shard_range(F, 0, world)
+            chk.accumulateFrames(disp[a:b], bgr[a:b], poses[a:b])
+            cnt, st = chk.cloudBigPartition(gmin, gmax, world)
+            assert st == 0 and list(cnt) == rows[0]
+        raws, starts, moved = [], [], []
+        for r, c in enumerate(ctxs):
+            n_local = int(hcounts[r])
+            n_before, n_after = int(sends[:r, r].sum()), int(sends[r + 1:, r].sum())
+            moves = not (n_before == 0 and n_after == 0 and sends[r, r] == n_local)
+            before_ptr = c.cloudBigRawView().data_ptr()
+            c.cloudBigAssumeSize(n_local)
+            starts.append(c.cloudBigPlaceSlices(r, rows[r], n_before, n_after))
+            raws.append(c.cloudBigRawView())
+            moved.append(moves)
+            assert (raws[-1].data_ptr() != before_ptr) == moves  # (nothing to move: the cloud stays where it is)
+            assert starts[-1] == n_before + sends[r, r] + n_after
+        torch.cuda.synchronize()
+        for r, c in enumerate(ctxs):  # "all-to-all": rank r's incoming segments, in source-rank order, into its gaps
+            lo, hi = 0, int(sends[:r, r].sum()) + int(sends[r, r])
+            for src in range(world):
+                if src == r:
+                    continue
+                n = int(sends[src, r])
+                off = starts[src] + int(sum(sends[src, q] for q in range(r) if q != src))
+                seg = raws[src][off: off + n]
+                if src < r:
+                    raws[r][lo: lo + n] = seg
+                    lo += n
+                else:
+                    raws[r][hi: hi + n] = seg
+                    hi += n
+        torch.cuda.synchronize()
+        outs = []
+        for r, c in enumerate(ctxs):
+            n_recv = int(sends[:, r].sum())
+            if moved[r]:
+                c.cloudBigSetSize(n_recv)
+            assert c.cloudBigSize()[0] == n_recv
+            outs.append(c.finalize(gmin=gmin, gmax=gmax))
+        assert_points_equal(np.concatenate(outs), ref, f"two-phase partition by hand, {world} virtual ranks")
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def _local_exchange(Qs, disp, bgr, poses, prm, world, fail=None, gather=True):
     """o3dr_merge_partitioned's own code with `world` ranks on one GPU: one context and one host thread per rank, joined
     by the test-only LOCAL transport (include/o3dr_testing.h) instead of RCCL, which refuses two ranks on one device.
