@@ -89,6 +89,14 @@ def test_multi_gpu_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.o3dr_cloud_big_header_dev(None, None) == -1
     assert L.o3dr_cloud_big_partition_dev(None, None, 1, 1, None) == -1
     assert L.o3dr_cloud_big_assume_size(None, 0) == -1
+    # the two-phase partition, the exchange's statistics and the test transport: same rule
+    assert L.o3dr_cloud_big_slice_counts_dev(None, None, 1, 1, None) == -1
+    off = C.c_int64(5)
+    assert L.o3dr_cloud_big_place_slices(None, 1, 0, None, 0, 0, C.byref(off)) == -1
+    assert L.o3dr_cloud_big_set_size(None, 0) == -1 and L.o3dr_cloud_big_raw_view(None, None, None) == -1
+    assert L.o3dr_merge_partitioned_stats(None, None) == -1 and L.o3dr_cloud_big_capacity(None, None, None) == -1
+    assert L.o3dr_test_merge_partitioned_local(None, None, 0, 1, None, 0, C.byref(n), C.byref(tot), C.byref(st), 0) == -1
+    assert L.o3dr_test_fail_at(None, 1) == -1 and L.o3dr_test_local_comm_create(0, None) == -1
     assert L.o3dr_comm_init_all(0, None, None) == -1
     assert L.o3dr_comm_destroy(None) == 0
     assert L.o3dr_host_register(None, 0) == -1 and L.o3dr_host_unregister(None) == 0
